@@ -1,0 +1,224 @@
+/*
+ * streamz_hip.h -- C ABI of libstreamz_hip.so, the MI355X (gfx950) implementation of the
+ * StreamZ feature-extraction + SimpleNeuralNet path.
+ *
+ * The reference has no FFI layer; its boundary for this path is the public Rust API of crate
+ * streamz_rs.  Every entry point below names the reference item it stands in for
+ * (paths under streamz-rs/src/).  A Rust shim with the reference signatures is a 1:1
+ * wrapper over these calls.
+ *
+ * Conventions
+ *   - every function returns 0 on success and a negative SZH_E* code on failure;
+ *     szh_last_error() returns a thread-local message for the last failure on this thread;
+ *   - nothing throws or aborts across the boundary;
+ *   - matrices are flat, row-major, caller-owned; outputs are caller-allocated and sized by
+ *     a query (szh_window_count, szh_net_output_size, ...);
+ *   - "host" pointers are ordinary memory; pointers in *_dev functions are device memory of
+ *     the current HIP device and `stream` is a hipStream_t passed as void* (NULL = the
+ *     default stream).  *_dev functions only enqueue work; they do not synchronise;
+ *   - thread-safety mirrors the reference: extract / forward / identify may be called
+ *     concurrently on one handle, calls that train one net must be serialised by the caller.
+ *   - there is no CPU fallback: every compute call fails with SZH_ENODEVICE when no HIP
+ *     device is usable.
+ */
+#ifndef STREAMZ_HIP_H
+#define STREAMZ_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SZH_OK 0
+#define SZH_EINVAL (-1)    /* bad argument (null pointer, shape mismatch, capacity too small) */
+#define SZH_ENODEVICE (-2) /* no usable HIP device / HIP runtime error */
+#define SZH_ENOMEM (-3)
+#define SZH_EIO (-4)       /* file missing, unreadable or malformed */
+#define SZH_EFORMAT (-5)   /* unsupported audio format (not 16-bit PCM WAV at 44.1 kHz) */
+
+#define SZH_FEATURE_SIZE 60   /* lib.rs:30-34 FEATURE_SIZE */
+#define SZH_MFCC_SIZE 20      /* lib.rs:28 */
+#define SZH_WINDOW_SIZE 800   /* lib.rs:26 */
+#define SZH_SAMPLE_RATE 44100 /* lib.rs:25 */
+
+typedef struct szh_extractor szh_extractor;
+typedef struct szh_plan szh_plan;
+typedef struct szh_net szh_net;
+
+/* ---- runtime ----------------------------------------------------------------------- */
+
+/* Select the HIP device this thread's later calls use (ordinal as in hipSetDevice). */
+int szh_init(int device_ordinal);
+const char *szh_last_error(void);
+/* free() for buffers this library returned (szh_load_cached_features, szh_wav_read). */
+void szh_free(void *p);
+
+/* ---- feature extraction ------------------------------------------------------------- */
+
+/* Number of 800-sample windows at hop 400 in n_samples samples: lib.rs:288-291, 317. */
+uint64_t szh_window_count(uint64_t n_samples);
+
+/* FeatureExtractor::new, lib.rs:239-258. */
+int szh_extractor_create(szh_extractor **ext);
+void szh_extractor_destroy(szh_extractor *ext);
+/* The 26 x 401 mel filterbank the extractor uses (lib.rs:240-248), row-major. */
+int szh_extractor_mel_filters(const szh_extractor *ext, float *out);
+
+/* FeatureExtractor::extract, lib.rs:261-263 -> window_samples_with_plan, lib.rs:279-345.
+ * pcm: n_samples mono 16-bit samples (host).  out: capacity_windows * 60 floats (host).
+ * *n_windows receives szh_window_count(n_samples); fails with SZH_EINVAL if that exceeds
+ * capacity_windows.  n_samples < 800 gives zero windows and success. */
+int szh_extract(szh_extractor *ext, const int16_t *pcm, uint64_t n_samples, float *out,
+                uint64_t capacity_windows, uint64_t *n_windows);
+
+/* The file-parallel extraction loop of main.rs:500-508 in one call: file f is
+ * pcm[f][0 .. n_samples[f]) and its windows go to out[f] (capacity szh_window_count each). */
+int szh_extract_batch(szh_extractor *ext, const int16_t *const *pcm, const uint64_t *n_samples,
+                      uint32_t n_files, float *const *out);
+
+/* Same loop with the audio already resident in device memory.  A plan fixes the file layout:
+ * file f occupies samples [offsets[f], offsets[f] + n_samples[f]) of one device PCM buffer;
+ * every offset must be a multiple of 8 samples.  Features of all files are written
+ * back to back, file f starting at window szh_plan_window_offsets()[f]. */
+int szh_plan_create(szh_extractor *ext, const uint64_t *offsets, const uint64_t *n_samples,
+                    uint32_t n_files, szh_plan **plan);
+void szh_plan_destroy(szh_plan *plan);
+uint64_t szh_plan_total_windows(const szh_plan *plan);
+/* out receives n_files + 1 prefix sums of the per-file window counts. */
+int szh_plan_window_offsets(const szh_plan *plan, uint64_t *out);
+/* Enqueue the extraction kernels.  feats_dev: total_windows * 60 floats.  No allocation,
+ * no host copy, no synchronisation. */
+int szh_plan_run_dev(szh_plan *plan, const int16_t *pcm_dev, float *feats_dev, void *stream);
+
+/* ---- SimpleNeuralNet ---------------------------------------------------------------- */
+
+/* SimpleNeuralNet::new(input, hidden1, hidden2, output), lib.rs:767-790.
+ * init: NULL -> weights ~ U(-0.5, 0.5) from `seed`, biases 0 (the reference draws from an
+ * unseeded thread RNG); otherwise the flat parameter vector [w1|b1|w2|b2|w3|b3] with
+ * w1[input][hidden1], w2[hidden1][hidden2], w3[hidden2][output] row-major. */
+int szh_net_create(uint32_t input, uint32_t hidden1, uint32_t hidden2, uint32_t output,
+                   const float *init, uint64_t seed, szh_net **net);
+void szh_net_destroy(szh_net *net);
+/* Clone (the reference derives Clone, lib.rs:744). */
+int szh_net_clone(const szh_net *net, szh_net **out);
+/* dims[4] = input, hidden1, hidden2, output.  output == SimpleNeuralNet::output_size, lib.rs:792. */
+int szh_net_dims(const szh_net *net, uint32_t dims[4]);
+uint32_t szh_net_output_size(const szh_net *net);
+uint64_t szh_net_param_count(const szh_net *net);
+int szh_net_get_params(szh_net *net, float *flat);
+int szh_net_set_params(szh_net *net, const float *flat);
+/* SimpleNeuralNet::add_output_class, lib.rs:797-821.  new_col: hidden2 weights of the new
+ * column, or NULL to draw them ~ U(-0.5, 0.5) from `seed`.  The new bias is 0. */
+int szh_net_add_output_class(szh_net *net, const float *new_col, uint64_t seed);
+
+/* SimpleNeuralNet::forward, lib.rs:880-891, for B rows at once.  x[B][input] ->
+ * probs[B][output] (softmax probabilities). */
+int szh_net_forward(szh_net *net, const float *x, uint64_t B, float *probs);
+/* SimpleNeuralNet::embed, lib.rs:895-900 (tanh hidden layer) -> emb[B][hidden2]. */
+int szh_net_embed(szh_net *net, const float *x, uint64_t B, float *emb);
+/* SimpleNeuralNet::forward_embedding, lib.rs:1073-1079 (ReLU on both layers). */
+int szh_net_forward_embedding(szh_net *net, const float *x, uint64_t B, float *emb);
+/* SimpleNeuralNet::train, lib.rs:954-999 (one sample, scale = lr). */
+int szh_net_train(szh_net *net, const float *x, const float *target, float lr);
+/* SimpleNeuralNet::train_batch, lib.rs:1002-1060.  target[output] is shared by the batch;
+ * B == 0 is a no-op. */
+int szh_net_train_batch(szh_net *net, const float *x, uint64_t B, const float *target, float lr);
+
+/* Optional injected random streams for szh_pretrain_from_features (the reference uses an
+ * unseeded thread RNG, lib.rs:596, 123; tests inject the streams to compare step by step).
+ *   perm : NULL or [epochs][n_windows], row order of each epoch after the shuffle (lib.rs:601)
+ *   keep : NULL or [epochs][n_windows][60] in shuffled order; 0 = element zeroed by
+ *          apply_dropout (lib.rs:119-129)
+ *   seed : used for whichever stream is NULL */
+typedef struct szh_rng {
+    const uint32_t *perm;
+    const uint8_t *keep;
+    uint64_t seed;
+} szh_rng;
+
+/* pretrain_from_features, lib.rs:582-628: the per-file epoch loop (shuffle, chunks of
+ * batch_size, input dropout without rescale, all-zero rows skipped, loss with the
+ * pre-update weights, train_batch on the survivors).  windows[n_windows][60] (host).
+ * *mean_loss = mean loss over all counted windows, 0 if none. */
+int szh_pretrain_from_features(szh_net *net, const float *windows, uint64_t n_windows,
+                               uint32_t target_class, uint32_t num_classes, uint32_t epochs, float lr,
+                               float dropout, uint32_t batch_size, const szh_rng *rng, float *mean_loss);
+
+/* train_from_feature_map, lib.rs:632-665: pretrain_from_features over files in list order
+ * with num_classes = output_size; feats[f][n_windows[f]][60]; a NULL feats[f] is a file
+ * missing from the map and is skipped.  *mean_loss = mean of the per-file losses. */
+int szh_train_from_feature_map(szh_net *net, const float *const *feats, const uint64_t *n_windows,
+                               const uint32_t *classes, uint32_t n_files, uint32_t epochs, float lr,
+                               float dropout, uint32_t batch_size, uint64_t seed, float *mean_loss);
+
+/* identify_speaker_list, lib.rs:1383-1411.  ids (capacity >= output_size) receives the
+ * speakers with at least one window whose top probability is >= threshold, by vote count
+ * descending (ties keep ascending id); per window the LAST maximum wins. */
+int szh_identify_speaker_list(szh_net *net, szh_extractor *ext, const int16_t *pcm, uint64_t n_samples,
+                              float threshold, uint32_t *ids, uint32_t capacity, uint32_t *n_ids);
+/* The same vote on feature rows already extracted (loop body of lib.rs:1391-1402).
+ * counts (optional, output_size entries) receives the per-speaker vote counts. */
+int szh_identify_from_features(szh_net *net, const float *feats, uint64_t n_windows, float threshold,
+                               uint32_t *ids, uint32_t capacity, uint32_t *n_ids, uint64_t *counts);
+
+/* ---- device-resident training / inference (multi-GPU building blocks) --------------- */
+/* One optimiser step is: zero_grad, accumulate over any number of feature blocks (here or on
+ * other ranks), all-reduce the gradient vector across ranks (caller, e.g. RCCL), apply.
+ * The gradient vector is param_count floats laid out like the parameters, followed by two
+ * floats: the summed loss and the count of live rows. */
+uint64_t szh_net_grad_len(const szh_net *net); /* param_count + 2 */
+float *szh_net_grad_dev(szh_net *net);
+int szh_net_zero_grad_dev(szh_net *net, void *stream);
+/* Forward + backward of n rows with per-row labels, weights frozen, sums added into the
+ * gradient vector (same arithmetic as the body of lib.rs:1013-1045 per row).
+ * dropout > 0 zeroes input elements with that probability from a counter-based generator
+ * keyed by (seed, row index); rows that end all-zero are skipped (lib.rs:607-609). */
+int szh_net_accumulate_dev(szh_net *net, const float *feats_dev, const int32_t *labels_dev, uint64_t n,
+                           float dropout, uint64_t seed, void *stream);
+/* params -= (lr / live_rows) * grad, lib.rs:1047-1059, reading live_rows from the vector's
+ * tail (so after an all-reduce it is the global count).  No-op when live_rows == 0. */
+int szh_net_apply_grad_dev(szh_net *net, float lr, void *stream);
+int szh_net_forward_dev(szh_net *net, const float *feats_dev, uint64_t n, float *probs_dev, void *stream);
+/* Votes of identify_speaker_list over device-resident feature rows: counts_dev[output]
+ * (uint64) is incremented; the caller zeroes it and orders the result. */
+int szh_net_vote_dev(szh_net *net, const float *feats_dev, uint64_t n, float threshold,
+                     unsigned long long *counts_dev, void *stream);
+
+/* ---- model metadata and persistence -------------------------------------------------- */
+
+/* record_training_file, lib.rs:855-862; file_lists, lib.rs:865-867. */
+int szh_net_record_training_file(szh_net *net, uint32_t speaker, const char *path);
+/* Newline-joined paths of one speaker; returns the byte length (without NUL) or a negative
+ * error; copies at most capacity-1 bytes and NUL-terminates when buf != NULL. */
+int64_t szh_net_file_list(const szh_net *net, uint32_t speaker, char *buf, uint64_t capacity);
+/* set_dataset_specs, lib.rs:823-826. */
+int szh_net_set_dataset_specs(szh_net *net, uint32_t sample_rate, uint16_t bits);
+/* set_embeddings / embeddings, lib.rs:870-877: n rows of (vector[dim], mean_sim, std_sim). */
+int szh_net_set_embeddings(szh_net *net, const float *vectors, const float *mean_sims,
+                           const float *std_sims, uint32_t n, uint32_t dim);
+int szh_net_get_embeddings(const szh_net *net, float *vectors, float *mean_sims, float *std_sims,
+                           uint32_t *n, uint32_t *dim);
+
+/* SimpleNeuralNet::save / load, lib.rs:1081-1130 / 1132-1281: model.npz, an uncompressed zip
+ * of .npy members (w1, b1, w2, b2, sample_rate, bits, num_speakers, w3_i / b3_i per class
+ * (1-based), speaker_i_files (0-based), speaker_embeddings, speaker_mean_sims,
+ * speaker_std_sims). */
+int szh_net_save(szh_net *net, const char *path);
+int szh_net_load(const char *path, szh_net **net);
+
+/* load_cached_features, lib.rs:558-579: feature_cache/<path with / and \ replaced by _>.npy
+ * ((n, 60) float32, C order); on a miss the audio is read (16-bit PCM WAV, 44.1 kHz,
+ * channels averaged, lib.rs:517-529, 172-183), extracted and the cache written (write
+ * errors ignored, empty results not written).  *feats is malloc'd; release with szh_free. */
+int szh_load_cached_features(const char *path, szh_extractor *ext, float **feats, uint64_t *n_windows);
+
+/* WAV ingest alone (load_and_resample_file, lib.rs:509-529, wav arm at 44.1 kHz):
+ * *pcm is malloc'd mono int16; release with szh_free. */
+int szh_wav_read(const char *path, int16_t **pcm, uint64_t *n_samples);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STREAMZ_HIP_H */

@@ -1,0 +1,18 @@
+"""streamz_amd: ctypes access to libstreamz_hip.so, the MI355X implementation of the StreamZ
+MFCC + SimpleNeuralNet path.
+
+The compute lives in the shared library (HIP kernels behind a C ABI, include/streamz_hip.h).
+This package only loads it and mirrors the reference's public names for tests and the
+benchmark.  There is no CPU fallback: importing works without a GPU (so that symbols can be
+checked), but every compute call raises StreamzError when no HIP device is usable, and
+loading raises if the library has not been built.
+"""
+from ._capi import (FEATURE_SIZE, FeatureExtractor, Plan, SimpleNeuralNet, StreamzError, exported_symbols,
+                    identify_from_features, identify_speaker_list,
+                    lib, library_path, load_cached_features, pretrain_from_features, train_from_feature_map,
+                    wav_read, window_count)
+
+__all__ = ["FEATURE_SIZE", "FeatureExtractor", "Plan", "SimpleNeuralNet", "StreamzError", "exported_symbols",
+           "identify_from_features", "identify_speaker_list",
+           "lib", "library_path", "load_cached_features", "pretrain_from_features", "train_from_feature_map",
+           "wav_read", "window_count"]

@@ -1,0 +1,418 @@
+"""ctypes binding of include/streamz_hip.h.  Names follow the reference's Rust API
+(streamz-rs/src/lib.rs): FeatureExtractor, SimpleNeuralNet, pretrain_from_features,
+train_from_feature_map, identify_speaker_list, load_cached_features."""
+import ctypes as C
+import os
+
+import numpy as np
+
+FEATURE_SIZE = 60
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libstreamz_hip.so")
+_lib = None
+
+
+class StreamzError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"streamz_hip error {code}: {msg}")
+        self.code = code
+
+
+def library_path():
+    return _SO
+
+
+_SIGS = {
+    # name: (restype, argtypes)
+    "szh_init": (C.c_int, [C.c_int]),
+    "szh_last_error": (C.c_char_p, []),
+    "szh_free": (None, [C.c_void_p]),
+    "szh_window_count": (C.c_uint64, [C.c_uint64]),
+    "szh_extractor_create": (C.c_int, [C.POINTER(C.c_void_p)]),
+    "szh_extractor_destroy": (None, [C.c_void_p]),
+    "szh_extractor_mel_filters": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "szh_extract": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "szh_extract_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
+    "szh_plan_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]),
+    "szh_plan_destroy": (None, [C.c_void_p]),
+    "szh_plan_total_windows": (C.c_uint64, [C.c_void_p]),
+    "szh_plan_window_offsets": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "szh_plan_run_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "szh_net_create": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint64,
+                                 C.POINTER(C.c_void_p)]),
+    "szh_net_destroy": (None, [C.c_void_p]),
+    "szh_net_clone": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "szh_net_dims": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "szh_net_output_size": (C.c_uint32, [C.c_void_p]),
+    "szh_net_param_count": (C.c_uint64, [C.c_void_p]),
+    "szh_net_get_params": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "szh_net_set_params": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "szh_net_add_output_class": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),
+    "szh_net_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
+    "szh_net_embed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
+    "szh_net_forward_embedding": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
+    "szh_net_train": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float]),
+    "szh_net_train_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_float]),
+    "szh_pretrain_from_features": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32,
+                                             C.c_float, C.c_float, C.c_uint32, C.c_void_p, C.POINTER(C.c_float)]),
+    "szh_train_from_feature_map": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
+                                             C.c_float, C.c_float, C.c_uint32, C.c_uint64, C.POINTER(C.c_float)]),
+    "szh_identify_speaker_list": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_float, C.c_void_p,
+                                            C.c_uint32, C.POINTER(C.c_uint32)]),
+    "szh_identify_from_features": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_float, C.c_void_p, C.c_uint32,
+                                             C.POINTER(C.c_uint32), C.c_void_p]),
+    "szh_net_grad_len": (C.c_uint64, [C.c_void_p]),
+    "szh_net_grad_dev": (C.c_void_p, [C.c_void_p]),
+    "szh_net_zero_grad_dev": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "szh_net_accumulate_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_float, C.c_uint64,
+                                         C.c_void_p]),
+    "szh_net_apply_grad_dev": (C.c_int, [C.c_void_p, C.c_float, C.c_void_p]),
+    "szh_net_forward_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
+    "szh_net_vote_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_float, C.c_void_p, C.c_void_p]),
+    "szh_net_record_training_file": (C.c_int, [C.c_void_p, C.c_uint32, C.c_char_p]),
+    "szh_net_file_list": (C.c_int64, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64]),
+    "szh_net_set_dataset_specs": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint16]),
+    "szh_net_set_embeddings": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]),
+    "szh_net_get_embeddings": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32),
+                                         C.POINTER(C.c_uint32)]),
+    "szh_net_save": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "szh_net_load": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
+    "szh_load_cached_features": (C.c_int, [C.c_char_p, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
+    "szh_wav_read": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
+}
+
+
+def exported_symbols():
+    """Every entry point include/streamz_hip.h declares."""
+    return sorted(_SIGS)
+
+
+def lib():
+    """Load libstreamz_hip.so (built in-tree by __graft_entry__.build()); raise if it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            raise StreamzError(-2, f"{_SO} is not built; run `python -c 'import __graft_entry__ as g; g.build()'`")
+        L = C.CDLL(_SO)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise StreamzError(rc, (lib().szh_last_error() or b"").decode("utf-8", "replace"))
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def window_count(n_samples):
+    return int(lib().szh_window_count(int(n_samples)))
+
+
+class FeatureExtractor:
+    """FeatureExtractor (lib.rs:231-264)."""
+
+    def __init__(self):
+        h = C.c_void_p()
+        _check(lib().szh_extractor_create(C.byref(h)))
+        self._h = h
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().szh_extractor_destroy(self._h)
+            self._h = None
+
+    def mel_filters(self):
+        w = np.zeros((26, 401), np.float32)
+        _check(lib().szh_extractor_mel_filters(self._h, _p(w)))
+        return w
+
+    def extract(self, samples):
+        pcm = np.ascontiguousarray(samples, np.int16)
+        cap = window_count(pcm.size)
+        out = np.zeros((cap, FEATURE_SIZE), np.float32)
+        n = C.c_uint64()
+        _check(lib().szh_extract(self._h, _p(pcm), pcm.size, _p(out), cap, C.byref(n)))
+        assert n.value == cap
+        return out
+
+    def extract_batch(self, clips):
+        clips = [np.ascontiguousarray(c, np.int16) for c in clips]
+        outs = [np.zeros((window_count(c.size), FEATURE_SIZE), np.float32) for c in clips]
+        n = len(clips)
+        pp = (C.c_void_p * n)(*[c.ctypes.data for c in clips])
+        po = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
+        ln = np.array([c.size for c in clips], np.uint64)
+        _check(lib().szh_extract_batch(self._h, pp, _p(ln), n, po))
+        return outs
+
+
+class Plan:
+    """Device-resident extraction over a fixed file layout (szh_plan_*)."""
+
+    def __init__(self, extractor, offsets, lengths):
+        self._ext = extractor
+        off = np.ascontiguousarray(offsets, np.uint64)
+        ln = np.ascontiguousarray(lengths, np.uint64)
+        h = C.c_void_p()
+        _check(lib().szh_plan_create(extractor._h, _p(off), _p(ln), len(off), C.byref(h)))
+        self._h = h
+        self.n_files = len(off)
+        self.total_windows = int(lib().szh_plan_total_windows(h))
+        wo = np.zeros(self.n_files + 1, np.uint64)
+        _check(lib().szh_plan_window_offsets(h, _p(wo)))
+        self.window_offsets = wo
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().szh_plan_destroy(self._h)
+            self._h = None
+
+    def run(self, pcm_ptr, feats_ptr, stream=0):
+        _check(lib().szh_plan_run_dev(self._h, C.c_void_p(pcm_ptr), C.c_void_p(feats_ptr), C.c_void_p(stream)))
+
+
+class SimpleNeuralNet:
+    """SimpleNeuralNet (lib.rs:744-1282)."""
+
+    def __init__(self, input=None, hidden1=None, hidden2=None, output=None, init=None, seed=0, _handle=None):
+        if _handle is not None:
+            self._h = _handle
+            return
+        h = C.c_void_p()
+        flat = None
+        if init is not None:
+            flat = np.concatenate([np.asarray(a, np.float32).ravel() for a in init]) if isinstance(init, (list, tuple)) \
+                else np.ascontiguousarray(init, np.float32)
+        _check(lib().szh_net_create(input, hidden1, hidden2, output, _p(flat), seed, C.byref(h)))
+        self._h = h
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().szh_net_destroy(self._h)
+            self._h = None
+
+    # -- shape / parameters
+    def dims(self):
+        d = np.zeros(4, np.uint32)
+        _check(lib().szh_net_dims(self._h, _p(d)))
+        return tuple(int(v) for v in d)
+
+    def output_size(self):
+        return int(lib().szh_net_output_size(self._h))
+
+    def embedding_size(self):
+        return self.dims()[2]
+
+    def param_count(self):
+        return int(lib().szh_net_param_count(self._h))
+
+    def shapes(self):
+        i, h1, h2, o = self.dims()
+        return [(i, h1), (h1,), (h1, h2), (h2,), (h2, o), (o,)]
+
+    def get_flat(self):
+        flat = np.zeros(self.param_count(), np.float32)
+        _check(lib().szh_net_get_params(self._h, _p(flat)))
+        return flat
+
+    def get_params(self):
+        flat, out, pos = self.get_flat(), [], 0
+        for s in self.shapes():
+            n = int(np.prod(s))
+            out.append(flat[pos:pos + n].reshape(s).copy())
+            pos += n
+        return out
+
+    def set_params(self, params):
+        flat = np.concatenate([np.asarray(a, np.float32).ravel() for a in params])
+        assert flat.size == self.param_count()
+        _check(lib().szh_net_set_params(self._h, _p(flat)))
+
+    def clone(self):
+        h = C.c_void_p()
+        _check(lib().szh_net_clone(self._h, C.byref(h)))
+        return SimpleNeuralNet(_handle=h)
+
+    def add_output_class(self, new_col=None, seed=0):
+        col = np.ascontiguousarray(new_col, np.float32) if new_col is not None else None
+        _check(lib().szh_net_add_output_class(self._h, _p(col), seed))
+
+    # -- forward variants
+    def _fwd(self, fn, x, width):
+        x = np.ascontiguousarray(x, np.float32).reshape(-1, self.dims()[0])
+        out = np.zeros((x.shape[0], width), np.float32)
+        _check(fn(self._h, _p(x), x.shape[0], _p(out)))
+        return out
+
+    def forward(self, x):
+        return self._fwd(lib().szh_net_forward, x, self.output_size())
+
+    def embed(self, x):
+        return self._fwd(lib().szh_net_embed, x, self.dims()[2])
+
+    def forward_embedding(self, x):
+        return self._fwd(lib().szh_net_forward_embedding, x, self.dims()[2])
+
+    # -- training
+    def train(self, x, target, lr):
+        x = np.ascontiguousarray(x, np.float32)
+        t = np.ascontiguousarray(target, np.float32)
+        _check(lib().szh_net_train(self._h, _p(x), _p(t), lr))
+
+    def train_batch(self, batch, target, lr):
+        x = np.ascontiguousarray(batch, np.float32).reshape(-1, self.dims()[0])
+        t = np.ascontiguousarray(target, np.float32)
+        _check(lib().szh_net_train_batch(self._h, _p(x), x.shape[0], _p(t), lr))
+
+    # -- device-resident building blocks
+    def grad_len(self):
+        return int(lib().szh_net_grad_len(self._h))
+
+    def grad_ptr(self):
+        return int(lib().szh_net_grad_dev(self._h))
+
+    def zero_grad_dev(self, stream=0):
+        _check(lib().szh_net_zero_grad_dev(self._h, C.c_void_p(stream)))
+
+    def accumulate_dev(self, feats_ptr, labels_ptr, n, dropout=0.0, seed=0, stream=0):
+        _check(lib().szh_net_accumulate_dev(self._h, C.c_void_p(feats_ptr), C.c_void_p(labels_ptr), n, dropout, seed,
+                                            C.c_void_p(stream)))
+
+    def apply_grad_dev(self, lr, stream=0):
+        _check(lib().szh_net_apply_grad_dev(self._h, lr, C.c_void_p(stream)))
+
+    def forward_dev(self, feats_ptr, n, probs_ptr, stream=0):
+        _check(lib().szh_net_forward_dev(self._h, C.c_void_p(feats_ptr), n, C.c_void_p(probs_ptr), C.c_void_p(stream)))
+
+    def vote_dev(self, feats_ptr, n, threshold, counts_ptr, stream=0):
+        _check(lib().szh_net_vote_dev(self._h, C.c_void_p(feats_ptr), n, threshold, C.c_void_p(counts_ptr),
+                                      C.c_void_p(stream)))
+
+    # -- metadata / persistence
+    def record_training_file(self, speaker, path):
+        _check(lib().szh_net_record_training_file(self._h, speaker, path.encode()))
+
+    def file_lists(self):
+        out = []
+        for s in range(self.output_size()):
+            n = lib().szh_net_file_list(self._h, s, None, 0)
+            buf = C.create_string_buffer(int(n) + 1)
+            lib().szh_net_file_list(self._h, s, buf, int(n) + 1)
+            text = buf.value.decode()
+            out.append(text.split("\n") if text else [])
+        return out
+
+    def set_dataset_specs(self, sample_rate, bits):
+        _check(lib().szh_net_set_dataset_specs(self._h, sample_rate, bits))
+
+    def set_embeddings(self, embeds):
+        n = len(embeds)
+        dim = len(embeds[0][0]) if n else 0
+        v = np.array([e[0] for e in embeds], np.float32).reshape(n, dim)
+        m = np.array([e[1] for e in embeds], np.float32)
+        s = np.array([e[2] for e in embeds], np.float32)
+        _check(lib().szh_net_set_embeddings(self._h, _p(v), _p(m), _p(s), n, dim))
+
+    def embeddings(self):
+        n, dim = C.c_uint32(), C.c_uint32()
+        _check(lib().szh_net_get_embeddings(self._h, None, None, None, C.byref(n), C.byref(dim)))
+        v = np.zeros((n.value, dim.value), np.float32)
+        m = np.zeros(n.value, np.float32)
+        s = np.zeros(n.value, np.float32)
+        _check(lib().szh_net_get_embeddings(self._h, _p(v), _p(m), _p(s), C.byref(n), C.byref(dim)))
+        return [(v[i], float(m[i]), float(s[i])) for i in range(n.value)]
+
+    def save(self, path):
+        _check(lib().szh_net_save(self._h, os.fsencode(path)))
+
+    @staticmethod
+    def load(path):
+        h = C.c_void_p()
+        _check(lib().szh_net_load(os.fsencode(path), C.byref(h)))
+        return SimpleNeuralNet(_handle=h)
+
+
+class _Rng(C.Structure):
+    _fields_ = [("perm", C.c_void_p), ("keep", C.c_void_p), ("seed", C.c_uint64)]
+
+
+def pretrain_from_features(net, windows, target_class, num_classes, epochs, lr, dropout, batch_size,
+                           perm=None, keep=None, seed=0):
+    """pretrain_from_features (lib.rs:582-628); perm/keep inject the shuffle and dropout streams."""
+    w = np.ascontiguousarray(windows, np.float32).reshape(-1, FEATURE_SIZE)
+    pm = np.ascontiguousarray(perm, np.uint32) if perm is not None else None
+    kp = np.ascontiguousarray(keep, np.uint8) if keep is not None else None
+    rng = _Rng(pm.ctypes.data if pm is not None else None, kp.ctypes.data if kp is not None else None, seed)
+    loss = C.c_float()
+    _check(lib().szh_pretrain_from_features(net._h, _p(w), w.shape[0], target_class, num_classes, epochs, lr, dropout,
+                                            batch_size, C.byref(rng), C.byref(loss)))
+    return float(loss.value)
+
+
+def train_from_feature_map(net, feature_map, files, epochs, lr, dropout, batch_size, seed=0):
+    """train_from_feature_map (lib.rs:632-665): files is a list of (path, class)."""
+    arrs = [np.ascontiguousarray(feature_map[p], np.float32).reshape(-1, FEATURE_SIZE) if p in feature_map else None
+            for p, _ in files]
+    n = len(files)
+    ptrs = (C.c_void_p * n)(*[a.ctypes.data if a is not None else None for a in arrs])
+    nw = np.array([a.shape[0] if a is not None else 0 for a in arrs], np.uint64)
+    cls = np.array([c for _, c in files], np.uint32)
+    loss = C.c_float()
+    _check(lib().szh_train_from_feature_map(net._h, ptrs, _p(nw), _p(cls), n, epochs, lr, dropout, batch_size, seed,
+                                            C.byref(loss)))
+    for (p, c), a in zip(files, arrs):
+        if a is not None:
+            net.record_training_file(c, p)  # lib.rs:655
+    return float(loss.value)
+
+
+def identify_speaker_list(net, sample, threshold, extractor):
+    """identify_speaker_list (lib.rs:1383-1411)."""
+    pcm = np.ascontiguousarray(sample, np.int16)
+    cap = max(net.output_size(), 1)
+    ids = np.zeros(cap, np.uint32)
+    n = C.c_uint32()
+    _check(lib().szh_identify_speaker_list(net._h, extractor._h, _p(pcm), pcm.size, threshold, _p(ids), cap,
+                                           C.byref(n)))
+    return [int(v) for v in ids[:n.value]]
+
+
+def identify_from_features(net, feats, threshold):
+    f = np.ascontiguousarray(feats, np.float32).reshape(-1, FEATURE_SIZE)
+    cap = max(net.output_size(), 1)
+    ids = np.zeros(cap, np.uint32)
+    counts = np.zeros(cap, np.uint64)
+    n = C.c_uint32()
+    _check(lib().szh_identify_from_features(net._h, _p(f), f.shape[0], threshold, _p(ids), cap, C.byref(n), _p(counts)))
+    return [int(v) for v in ids[:n.value]], counts[:net.output_size()].copy()
+
+
+def load_cached_features(path, extractor):
+    """load_cached_features (lib.rs:558-579)."""
+    ptr, n = C.c_void_p(), C.c_uint64()
+    _check(lib().szh_load_cached_features(os.fsencode(path), extractor._h, C.byref(ptr), C.byref(n)))
+    try:
+        arr = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_float)), shape=(n.value * FEATURE_SIZE,)).copy() \
+            if n.value else np.zeros(0, np.float32)
+    finally:
+        lib().szh_free(ptr)
+    return arr.reshape(n.value, FEATURE_SIZE)
+
+
+def wav_read(path):
+    ptr, n = C.c_void_p(), C.c_uint64()
+    _check(lib().szh_wav_read(os.fsencode(path), C.byref(ptr), C.byref(n)))
+    try:
+        arr = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_int16)), shape=(n.value,)).copy() if n.value \
+            else np.zeros(0, np.int16)
+    finally:
+        lib().szh_free(ptr)
+    return arr

@@ -1,0 +1,263 @@
+// MFCC + delta + delta-delta + z-score extraction on gfx950.
+//
+// Two kernels:
+//   mfcc_base_kernel  PCM -> 20 un-normalised MFCCs per window (reference lib.rs:292-315).
+//                     A wavefront works on 6 windows at a time, 10 lanes per window; the
+//                     800-point real DFT is a 400-point complex FFT done as two register
+//                     passes of 20-point DFTs with one exchange through LDS (see
+//                     extract_phases.h).  Waves never synchronise with each other.
+//   finish_kernel     deltas with edge replication at file boundaries, concat and per-frame
+//                     z-score (lib.rs:212-228, 321-342); streams 80 B in, 240 B out per window.
+#include "extract_phases.h"
+#include "internal.h"
+#include "streamz_hip.h"
+
+namespace sz {
+
+namespace {
+
+// Lanes of one wavefront exchange data through LDS between phases.  LDS operations of a
+// wavefront execute in program order, so only the compiler has to be stopped from moving
+// accesses across the phase boundary.
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+constexpr int kBaseThreads = 256;
+constexpr int kBaseWaves = kBaseThreads / 64;
+constexpr size_t kBaseLdsBytes = (size_t)kBaseWaves * kWinPerWave * kRegionFloats * sizeof(float);
+
+__global__ __launch_bounds__(kBaseThreads, 2) void mfcc_base_kernel(const int16_t* __restrict__ pcm,
+                                                                  const Segment* __restrict__ segs,
+                                                                  uint32_t n_segs,
+                                                                  const ExtractTables* __restrict__ T,
+                                                                  float* __restrict__ base)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    // lanes 60..63 shadow lanes 50..53: same inputs, same LDS writes, no global store
+    const int slot = lane < 60 ? lane : lane - 10;
+    const int grp = slot / kGroup;
+    const int u = slot - grp * kGroup;
+    float* R = lds + (wave * kWinPerWave + grp) * kRegionFloats;
+    const uint32_t waves_total = gridDim.x * kBaseWaves;
+    for (uint32_t sg = blockIdx.x * kBaseWaves + wave; sg < n_segs; sg += waves_total) {
+        const Segment S = segs[sg];
+        for (uint32_t w0 = 0; w0 < S.n_win; w0 += kWinPerWave) {
+            uint32_t wi = w0 + grp;
+            const bool valid = wi < S.n_win;
+            if (!valid) wi = S.n_win - 1;
+            const int16_t* win = pcm + S.pcm_off + (uint64_t)wi * kHop;
+            // The tables are re-read (from L1 / the scalar cache) in every iteration: letting
+            // the compiler hoist ~250 loop-invariant twiddle loads into registers spills.
+            // (The opaque value is an offset, not the pointer, so the loads stay global_load.)
+            uint32_t opaque0 = 0;
+            asm volatile("" : "+s"(opaque0));
+            phase1(u, win, R, T + opaque0);
+            wave_sync();
+            asm volatile("" : "+s"(opaque0));
+            phase2(u, R, T + opaque0);
+            wave_sync();
+            asm volatile("" : "+s"(opaque0));
+            phase3(u, R, T + opaque0);
+            wave_sync();
+            phase4(u, R, T + opaque0);
+            wave_sync();
+            asm volatile("" : "+s"(opaque0));
+            float c_lo, c_hi;
+            phase5(u, R, T + opaque0, c_lo, c_hi);
+            if (valid && lane < 60) {
+                float* o = base + (S.win_first + wi) * kMfcc;
+                o[u] = c_lo;
+                o[u + 10] = c_hi;
+            }
+            wave_sync();
+        }
+    }
+}
+
+constexpr int kFinishThreads = kSegWindows * 4;
+
+__device__ __forceinline__ float quad_sum(float v)
+{
+    v += __shfl_xor(v, 1);
+    v += __shfl_xor(v, 2);
+    return v;
+}
+
+__global__ __launch_bounds__(kFinishThreads) void finish_kernel(const float* __restrict__ base,
+                                                               const Segment* __restrict__ segs,
+                                                               uint32_t n_segs, float* __restrict__ out)
+{
+    __shared__ __attribute__((aligned(16))) float F[kSegWindows * kFeat];
+    const int f = threadIdx.x >> 2;
+    const int p = threadIdx.x & 3;
+    for (uint32_t sg = blockIdx.x; sg < n_segs; sg += gridDim.x) {
+        const Segment S = segs[sg];
+        const bool active = (uint32_t)f < S.n_win;
+        const int64_t n = (int64_t)S.file_n_win;
+        const int64_t t = active ? (int64_t)(S.win_first - S.file_win_first) + f : 0;
+        const float* fb = base + S.file_win_first * kMfcc;
+        // rows t-2 .. t+2 with the edge rule of add_deltas (lib.rs:215-220) applied twice
+        const int64_t tm1 = t > 0 ? t - 1 : t;
+        const int64_t tp1 = t + 1 < n ? t + 1 : t;
+        const int64_t tm1m = tm1 > 0 ? tm1 - 1 : tm1;
+        const int64_t tm1p = tm1 + 1 < n ? tm1 + 1 : tm1;
+        const int64_t tp1m = tp1 > 0 ? tp1 - 1 : tp1;
+        const int64_t tp1p = tp1 + 1 < n ? tp1 + 1 : tp1;
+        float c[5], d[5], dd[5];
+        float sum = 0.0f;
+#pragma unroll
+        for (int jj = 0; jj < 5; ++jj) {
+            const int j = 5 * p + jj;
+            c[jj] = fb[t * kMfcc + j];
+            d[jj] = (fb[tp1 * kMfcc + j] - fb[tm1 * kMfcc + j]) / 2.0f;
+            const float d_next = (fb[tp1p * kMfcc + j] - fb[tp1m * kMfcc + j]) / 2.0f;
+            const float d_prev = (fb[tm1p * kMfcc + j] - fb[tm1m * kMfcc + j]) / 2.0f;
+            dd[jj] = (d_next - d_prev) / 2.0f;
+            sum += c[jj] + d[jj] + dd[jj];
+        }
+        const float mean = quad_sum(sum) / (float)kFeat;
+        float vs = 0.0f;
+#pragma unroll
+        for (int jj = 0; jj < 5; ++jj) {
+            const float a = c[jj] - mean, b = d[jj] - mean, e = dd[jj] - mean;
+            vs += a * a + b * b + e * e;
+        }
+        const float var = quad_sum(vs) / (float)kFeat;
+        const float sd = fmaxf(sqrtf(var), 1e-6f);
+        if (active) {
+#pragma unroll
+            for (int jj = 0; jj < 5; ++jj) {
+                const int j = 5 * p + jj;
+                F[f * kFeat + j] = (c[jj] - mean) / sd;
+                F[f * kFeat + kMfcc + j] = (d[jj] - mean) / sd;
+                F[f * kFeat + 2 * kMfcc + j] = (dd[jj] - mean) / sd;
+            }
+        }
+        __syncthreads();
+        float4* dst = reinterpret_cast<float4*>(out + S.win_first * kFeat);
+        const float4* src = reinterpret_cast<const float4*>(F);
+        const int n4 = (int)S.n_win * (kFeat / 4);
+        for (int i = threadIdx.x; i < n4; i += kFinishThreads) dst[i] = src[i];
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+int extractor_create(Extractor** out)
+{
+    Extractor* e = new (std::nothrow) Extractor();
+    if (!e) { set_error("out of host memory"); return SZH_ENOMEM; }
+    const int rc = build_extract_tables(&e->host);
+    if (rc != 0) {
+        set_error("mel filterbank does not have the two-triangles-per-bin structure (code %d)", rc);
+        delete e;
+        return SZH_EINVAL;
+    }
+    hipError_t he = hipGetDevice(&e->device);
+    if (he == hipSuccess) he = hipMalloc((void**)&e->dev, sizeof(ExtractTables));
+    if (he == hipSuccess) he = hipMemcpy(e->dev, &e->host, sizeof(ExtractTables), hipMemcpyHostToDevice);
+    if (he != hipSuccess) {
+        if (e->dev) (void)hipFree(e->dev);
+        delete e;
+        return hip_fail(he, "extractor tables upload");
+    }
+    *out = e;
+    return SZH_OK;
+}
+
+void extractor_destroy(Extractor* e)
+{
+    if (!e) return;
+    if (e->dev) (void)hipFree(e->dev);
+    delete e;
+}
+
+int plan_create(Extractor* e, const uint64_t* offsets, const uint64_t* lengths, uint32_t n_files, Plan** out)
+{
+    Plan* p = new (std::nothrow) Plan();
+    if (!p) { set_error("out of host memory"); return SZH_ENOMEM; }
+    p->ext = e;
+    p->win_off.assign((size_t)n_files + 1, 0);
+    std::vector<Segment> segs;
+    for (uint32_t f = 0; f < n_files; ++f) {
+        if (offsets[f] % 8 != 0) {
+            set_error("file %u: offset %llu is not a multiple of 8 samples", f, (unsigned long long)offsets[f]);
+            delete p;
+            return SZH_EINVAL;
+        }
+        const uint64_t nw = szh_window_count(lengths[f]);
+        p->win_off[f + 1] = p->win_off[f] + nw;
+        if (offsets[f] + lengths[f] > p->pcm_extent) p->pcm_extent = offsets[f] + lengths[f];
+        if (nw > 0xffffffffull) {
+            set_error("file %u has more than 2^32 windows", f);
+            delete p;
+            return SZH_EINVAL;
+        }
+        for (uint64_t w = 0; w < nw; w += kSegWindows) {
+            Segment s;
+            s.pcm_off = offsets[f] + w * kHop;
+            s.win_first = p->win_off[f] + w;
+            s.file_win_first = p->win_off[f];
+            s.n_win = (uint32_t)(nw - w < kSegWindows ? nw - w : kSegWindows);
+            s.file_n_win = (uint32_t)nw;
+            segs.push_back(s);
+        }
+    }
+    p->total_windows = p->win_off[n_files];
+    if (segs.size() > 0xffffffffull) { set_error("too many segments"); delete p; return SZH_EINVAL; }
+    p->n_segs = (uint32_t)segs.size();
+    if (p->n_segs) {
+        hipError_t he = hipMalloc((void**)&p->d_segs, segs.size() * sizeof(Segment));
+        if (he == hipSuccess)
+            he = hipMemcpy(p->d_segs, segs.data(), segs.size() * sizeof(Segment), hipMemcpyHostToDevice);
+        if (he == hipSuccess) he = hipMalloc((void**)&p->d_base, p->total_windows * kMfcc * sizeof(float));
+        if (he != hipSuccess) {
+            plan_destroy(p);
+            return hip_fail(he, "plan allocation");
+        }
+    }
+    *out = p;
+    return SZH_OK;
+}
+
+void plan_destroy(Plan* p)
+{
+    if (!p) return;
+    if (p->d_segs) (void)hipFree(p->d_segs);
+    if (p->d_base) (void)hipFree(p->d_base);
+    delete p;
+}
+
+int plan_run(Plan* p, const int16_t* pcm_dev, float* feats_dev, hipStream_t stream)
+{
+    if (p->n_segs == 0) return SZH_OK;
+    if (((uintptr_t)pcm_dev & 15) != 0 || ((uintptr_t)feats_dev & 15) != 0) {
+        set_error("device buffers must be 16-byte aligned");
+        return SZH_EINVAL;
+    }
+    static bool attr_set = false;
+    if (!attr_set) {
+        SZ_HIP(hipFuncSetAttribute((const void*)mfcc_base_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)kBaseLdsBytes));
+        attr_set = true;
+    }
+    const uint32_t wave_jobs = (p->n_segs + kBaseWaves - 1) / kBaseWaves;
+    const uint32_t grid_a = wave_jobs < 256u * 2u * 8u ? wave_jobs : 256u * 2u * 8u;
+    hipLaunchKernelGGL(mfcc_base_kernel, dim3(grid_a), dim3(kBaseThreads), kBaseLdsBytes, stream, pcm_dev,
+                       p->d_segs, p->n_segs, p->ext->dev, p->d_base);
+    SZ_HIP(hipGetLastError());
+    const uint32_t grid_b = p->n_segs < 256u * 32u ? p->n_segs : 256u * 32u;
+    hipLaunchKernelGGL(finish_kernel, dim3(grid_b), dim3(kFinishThreads), 0, stream, p->d_base, p->d_segs,
+                       p->n_segs, feats_dev);
+    SZ_HIP(hipGetLastError());
+    return SZH_OK;
+}
+
+}  // namespace sz

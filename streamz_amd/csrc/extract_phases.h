@@ -1,0 +1,183 @@
+// The five per-lane phases of the MFCC base-coefficient kernel (framing, 800-point real DFT
+// as a 400-point complex FFT, power spectrum, mel filterbank, log, DCT-II) that restate
+// reference lib.rs:292-315.  A group of 10 lanes works on one window; the phases talk to each
+// other only through the window's scratch region R (LDS on the device, a plain array in the
+// CPU lane emulator of the unit tests), so running every lane of a group through phase N
+// before any lane starts phase N+1 is exactly what a wavefront does.
+//
+// Scratch region R, in floats (kRegionFloats per window):
+//   [0, 800)    Y[k1][n2] complex, row stride 40 floats       (phase 1 -> phase 2)
+//   [0, 404)    power spectrum P[0..400]                      (phase 2 -> phase 3; aliases Y)
+//   [404, 724)  mel partial sums, (fall, rise) pairs          (phase 3 -> phase 4)
+//   [724, 750)  log mel energies                              (phase 4 -> phase 5)
+#pragma once
+#include <math.h>
+#include <stdint.h>
+
+#include "extract_tables.h"
+#include "fftmath.h"
+
+namespace sz {
+
+constexpr int kRegionFloats = 800;
+constexpr int kRowFloats = 40;
+constexpr int kPartOff = 404;
+constexpr int kLogOff = 724;
+
+struct alignas(8) pcm4 { int16_t s[4]; };
+struct alignas(16) f4 { float v[4]; };
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SZ_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define SZ_SCHED_FENCE() ((void)0)
+#endif
+
+SZ_HD float lo16(uint32_t w) { return (float)(int16_t)(w & 0xffffu); }
+SZ_HD float hi16(uint32_t w) { return (float)(int16_t)(w >> 16); }
+
+// Phase 1: load this lane's samples of the window, two 20-point DFTs over n1, twiddle, store Y.
+// win points at the first sample of the window and must be 8-byte aligned.  The two columns
+// are transformed one after the other so that only one 20-point DFT is live in registers.
+SZ_HD void phase1(int u, const int16_t* win, float* R, const ExtractTables* T)
+{
+    uint32_t ra[20], rb[20];
+#pragma unroll
+    for (int n1 = 0; n1 < 20; ++n1) {
+        const pcm4 q = *reinterpret_cast<const pcm4*>(win + 40 * n1 + 4 * u);
+        ra[n1] = (uint32_t)(uint16_t)q.s[0] | ((uint32_t)(uint16_t)q.s[1] << 16);
+        rb[n1] = (uint32_t)(uint16_t)q.s[2] | ((uint32_t)(uint16_t)q.s[3] << 16);
+    }
+    {
+        v2f a[20], A[20];
+#pragma unroll
+        for (int n1 = 0; n1 < 20; ++n1) a[n1] = mk(lo16(ra[n1]), hi16(ra[n1]));
+        dft20(a, A);
+#pragma unroll
+        for (int k1 = 0; k1 < 20; ++k1) {
+            const v2f y = cmul(A[k1], mk(T->twa[k1][u][0], T->twa[k1][u][1]));
+            *reinterpret_cast<v2f*>(R + k1 * kRowFloats + 4 * u) = y;
+        }
+    }
+    SZ_SCHED_FENCE();
+    {
+        v2f b[20], B[20];
+#pragma unroll
+        for (int n1 = 0; n1 < 20; ++n1) b[n1] = mk(lo16(rb[n1]), hi16(rb[n1]));
+        dft20(b, B);
+#pragma unroll
+        for (int k1 = 0; k1 < 20; ++k1) {
+            const v2f y = cmul(B[k1], mk(T->twb[k1][u][0], T->twb[k1][u][1]));
+            *reinterpret_cast<v2f*>(R + k1 * kRowFloats + 4 * u + 2) = y;
+        }
+    }
+}
+
+SZ_HD void read_row(const float* R, int row, v2f (&x)[20])
+{
+#pragma unroll
+    for (int j = 0; j < 10; ++j) {
+        const f4 q = *reinterpret_cast<const f4*>(R + row * kRowFloats + 4 * j);
+        x[2 * j] = mk(q.v[0], q.v[1]);
+        x[2 * j + 1] = mk(q.v[2], q.v[3]);
+    }
+}
+
+// One split slot: from P = Z[k], Q = Z[400-k] (both already carrying the factor 1/2) to
+// |X[k]|^2 and |X[400-k]|^2 with X the 800-point DFT of the real window.
+SZ_HD void split_pair(v2f P, v2f Q, v2f w, float& pk, float& pn)
+{
+    const v2f cq = conj(Q);
+    const v2f A = P + cq;
+    const v2f B = mul_negi(cmul(w, P - cq));
+    const v2f X = A + B, Xn = A - B;
+    pk = X[0] * X[0] + X[1] * X[1];
+    pn = Xn[0] * Xn[0] + Xn[1] * Xn[1];
+}
+
+// Phase 2: two 20-point DFTs over n2, real-FFT split, power spectrum into R[0..400].
+SZ_HD void phase2(int u, float* R, const ExtractTables* T)
+{
+    const bool z = (u == 0);
+    v2f x[20], ZA[20], ZB[20];
+    read_row(R, z ? 0 : u, x);
+    dft20(x, ZA);
+    read_row(R, z ? 10 : 20 - u, x);
+    dft20(x, ZB);
+#pragma unroll
+    for (int s = 0; s < kSplitSlots; ++s) {
+        v2f P, Q;
+        if (s <= 10) {
+            P = ZA[s];
+            const v2f q0 = ZA[(20 - s) % 20], q1 = ZB[19 - s];
+            Q = mk(z ? q0[0] : q1[0], z ? q0[1] : q1[1]);
+        } else if (s <= 19) {
+            P = mk(z ? ZB[s][0] : ZA[s][0], z ? ZB[s][1] : ZA[s][1]);
+            Q = ZB[19 - s];
+        } else {
+            P = ZB[9];
+            Q = ZB[10];
+        }
+        const v2f w = mk(T->sw[s][u][0], T->sw[s][u][1]);
+        float pk, pn;
+        split_pair(P, Q, w, pk, pn);
+        const int k = T->kb[s][u];
+        if (s < 20 || z) {
+            R[k] = pk;
+            R[400 - k] = pn;
+        }
+    }
+}
+
+// Phase 3: this lane's 40 bins of the mel sweep.
+SZ_HD void phase3(int q, float* R, const ExtractTables* T)
+{
+    float af = 0.0f, ar = 0.0f;
+    int pair = 0;
+#pragma unroll 8
+    for (int st = 0; st < kMelSteps; ++st) {
+        const MelStep ms = T->mel[st][q];
+        const float p = R[kMelSteps * q + 1 + st];
+        af += ms.wf * p;
+        ar += ms.wr * p;
+        if (ms.flush) {
+            R[kPartOff + (q * kMaxPairs + pair) * 2 + 0] = af;
+            R[kPartOff + (q * kMaxPairs + pair) * 2 + 1] = ar;
+            ++pair;
+            af = 0.0f;
+            ar = 0.0f;
+        }
+    }
+}
+
+// Phase 4: recombine the partial sums of filters q, q+10, q+20 and take the clamped log
+// (lib.rs:309).
+SZ_HD void phase4(int q, float* R, const ExtractTables* T)
+{
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const int m = q + 10 * r;
+        if (m < kMels) {
+            float s = 0.0f;
+            const int n = T->comb_n[m];
+            for (int i = 0; i < n; ++i) s += R[kPartOff + T->comb_pos[m][i]];
+            R[kLogOff + m] = logf(fmaxf(s, 1e-12f));
+        }
+    }
+}
+
+// Phase 5: DCT-II coefficients q and q+10 (lib.rs:312-315).
+SZ_HD void phase5(int q, const float* R, const ExtractTables* T, float& c_lo, float& c_hi)
+{
+    float s0 = 0.0f, s1 = 0.0f;
+#pragma unroll
+    for (int n = 0; n < kMels; ++n) {
+        const float e = R[kLogOff + n];
+        s0 += e * T->dct2[n][q][0];
+        s1 += e * T->dct2[n][q][1];
+    }
+    c_lo = s0;
+    c_hi = s1;
+}
+
+}  // namespace sz

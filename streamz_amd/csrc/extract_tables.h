@@ -1,0 +1,66 @@
+// Constant tables of the MFCC extractor, built once on the host (FeatureExtractor::new,
+// reference lib.rs:239-258) and copied to the device as one blob.
+//
+// Geometry the tables encode.  One window (800 real samples) is transformed as a 400-point
+// complex FFT of z[n] = x[2n] + i*x[2n+1], decomposed 400 = 20 x 20 and worked on by a group
+// of 10 lanes ("u" = lane in group):
+//   pass 1  lane u owns columns n2 = 2u, 2u+1 and does two 20-point DFTs over n1,
+//           then multiplies by w400^(n2*k1) (tables twa/twb, which also carry the input
+//           scale 1/32767 of lib.rs:167-169 and the 1/2 of the real-FFT split);
+//   pass 2  lane u owns rows k1 = u and 20-u (lane 0: rows 0 and 10), two 20-point DFTs
+//           over n2, giving Z[k1 + 20*k2];
+//   split   21 slots per lane, each turning a pair (Z[k], Z[400-k]) into X[k], X[400-k]
+//           with the twiddle w800^k (table sw) and storing |X|^2 at bins k and 400-k
+//           (table kb gives k).
+// Mel: lane (window, q) sweeps bins 40q+1 .. 40q+40; each bin feeds the falling edge of one
+// triangle and the rising edge of the next (weights melw), partial sums are flushed when the
+// bin crosses a triangle centre and recombined per filter through comb_pos.
+#pragma once
+#include <stdint.h>
+
+namespace sz {
+
+constexpr int kWindow = 800;      // lib.rs:26
+constexpr int kHop = 400;         // lib.rs:288
+constexpr int kBins = 401;        // lib.rs:299
+constexpr int kMels = 26;         // lib.rs:27
+constexpr int kMfcc = 20;         // lib.rs:28
+constexpr int kFeat = 60;         // lib.rs:30-34
+constexpr int kSampleRate = 44100;  // lib.rs:25
+
+constexpr int kGroup = 10;        // lanes per window
+constexpr int kWinPerWave = 6;    // windows per wavefront iteration
+constexpr int kSplitSlots = 21;
+constexpr int kMelSteps = 40;
+constexpr int kMaxPairs = 16;     // partial (fall, rise) pairs per mel lane
+constexpr int kMaxComb = 8;
+
+struct MelStep {
+    float wf;       // weight into the falling-edge accumulator
+    float wr;       // weight into the rising-edge accumulator
+    int32_t flush;  // non-zero: store both accumulators as the next partial pair, then clear
+    int32_t pad;
+};
+
+struct ExtractTables {
+    float twa[20][kGroup][2];
+    float twb[20][kGroup][2];
+    float sw[kSplitSlots][kGroup][2];
+    int32_t kb[kSplitSlots][kGroup];
+    MelStep mel[kMelSteps][kGroup];
+    int32_t comb_n[32];
+    int32_t comb_pos[32][kMaxComb];   // float index into a window's partial array
+    float dct2[kMels][kGroup][2];     // (D[q][n], D[q+10][n]),  D[c][n] = cos(pi*(2n+1)*c/52)
+    float mel_dense[kMels][kBins];    // the full filterbank, kept for inspection / tests
+};
+
+// Fills *t.  Returns 0, or a negative number if the filterbank does not have the
+// "each bin feeds at most two adjacent triangles" structure the sweep relies on.
+int build_extract_tables(ExtractTables* t);
+
+// mel_filter::mel(44100, 800, Some(26), None, None, false, NormalizationFactor::One)
+// (reference lib.rs:240-248): Slaney scale, triangles, area normalisation, f32.
+// centres receives the 28 band edges in Hz.
+void build_mel_filterbank(float (*w)[kBins], float* centres);
+
+}  // namespace sz

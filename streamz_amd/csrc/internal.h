@@ -1,0 +1,124 @@
+// Internal declarations shared by the translation units of libstreamz_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "extract_tables.h"
+
+namespace sz {
+
+// ---- error plumbing ------------------------------------------------------------------
+void set_error(const char* fmt, ...);
+int hip_fail(hipError_t e, const char* what);  // records the message, returns SZH_ENODEVICE
+#define SZ_HIP(expr)                                          \
+    do {                                                      \
+        hipError_t e__ = (expr);                              \
+        if (e__ != hipSuccess) return ::sz::hip_fail(e__, #expr); \
+    } while (0)
+
+// ---- extraction ----------------------------------------------------------------------
+// One unit of kernel work: up to kSegWindows consecutive windows of one file.
+constexpr uint32_t kSegWindows = 48;
+struct Segment {
+    uint64_t pcm_off;         // first sample of the segment's first window in the PCM buffer
+    uint64_t win_first;       // global index of the segment's first window
+    uint64_t file_win_first;  // global index of the owning file's first window
+    uint32_t n_win;           // windows in this segment (1..kSegWindows)
+    uint32_t file_n_win;      // windows in the owning file
+};
+
+struct Extractor {
+    ExtractTables host;
+    ExtractTables* dev = nullptr;
+    int device = 0;
+};
+
+struct Plan {
+    Extractor* ext = nullptr;
+    std::vector<uint64_t> win_off;  // n_files + 1 prefix sums
+    uint64_t total_windows = 0;
+    uint64_t pcm_extent = 0;        // samples the plan may read: max(offset + length)
+    uint32_t n_segs = 0;
+    Segment* d_segs = nullptr;
+    float* d_base = nullptr;        // [total_windows][20] un-normalised MFCCs
+};
+
+int extractor_create(Extractor** out);
+void extractor_destroy(Extractor* e);
+int plan_create(Extractor* e, const uint64_t* offsets, const uint64_t* lengths, uint32_t n_files, Plan** out);
+void plan_destroy(Plan* p);
+int plan_run(Plan* p, const int16_t* pcm_dev, float* feats_dev, hipStream_t stream);
+
+// ---- network -------------------------------------------------------------------------
+struct Workspace {
+    uint64_t rows = 0;  // capacity in rows
+    uint32_t out = 0;   // output width it was sized for
+    float *xd = nullptr, *h1 = nullptr, *h2 = nullptr, *p = nullptr, *d2 = nullptr, *d1 = nullptr, *slab = nullptr;
+    uint8_t* live = nullptr;
+    uint64_t slab_floats = 0;
+};
+
+struct Net {
+    uint32_t in = 0, h1 = 0, h2 = 0, out = 0;
+    float* d_params = nullptr;  // [w1|b1|w2|b2|w3|b3]
+    float* d_grad = nullptr;    // same layout + {loss_sum, live_rows}
+    double* d_stats = nullptr;  // {loss, live rows} since zero_grad, then the same as running totals
+    std::mutex mu;              // serialises host-API calls that share the workspace
+    Workspace ws;
+    int device = 0;
+    // metadata carried by model.npz (lib.rs:755-761)
+    std::vector<std::vector<std::string>> file_lists;
+    uint32_t sample_rate = 44100;
+    uint16_t bits = 16;
+    std::vector<float> emb_vectors, emb_mean, emb_std;
+    uint32_t emb_dim = 0;
+    // optional w4/b4 "encoding layer" columns are preserved through load/save untouched
+    std::vector<std::vector<float>> w4_cols;
+    std::vector<float> b4;
+
+    uint64_t off_w1() const { return 0; }
+    uint64_t off_b1() const { return (uint64_t)in * h1; }
+    uint64_t off_w2() const { return off_b1() + h1; }
+    uint64_t off_b2() const { return off_w2() + (uint64_t)h1 * h2; }
+    uint64_t off_w3() const { return off_b2() + h2; }
+    uint64_t off_b3() const { return off_w3() + (uint64_t)h2 * out; }
+    uint64_t param_count() const { return off_b3() + out; }
+};
+
+int net_create(uint32_t in, uint32_t h1, uint32_t h2, uint32_t out, const float* init, uint64_t seed, Net** net);
+void net_destroy(Net* n);
+int net_set_params(Net* n, const float* flat);
+int net_get_params(Net* n, float* flat);
+int net_add_output_class(Net* n, const float* col, uint64_t seed);
+
+enum ForwardKind { kFwdProbs = 0, kFwdEmbedTanh = 1, kFwdEmbedRelu = 2 };
+// x_dev[n][in] -> out_dev ([n][out] probabilities or [n][h2] embeddings)
+int net_forward_dev(Net* n, const float* x_dev, uint64_t rows, float* out_dev, ForwardKind kind, hipStream_t s);
+
+struct AccumArgs {
+    const float* x_dev = nullptr;       // [rows_src][in]
+    uint64_t rows = 0;                  // rows of this call
+    const uint32_t* perm_dev = nullptr; // optional: row r reads x_dev[perm[r]]
+    const uint8_t* keep_dev = nullptr;  // optional: [rows][in] explicit dropout mask (0 = zero it)
+    float dropout = 0.0f;               // used when keep_dev == nullptr
+    uint64_t seed = 0;                  // counter-based generator key
+    uint64_t row_counter0 = 0;          // counter of row 0 (keeps streams distinct across calls)
+    const float* target_dev = nullptr;  // [out] shared target, or
+    const int32_t* labels_dev = nullptr;// [rows] per-row class
+    bool skip_zero_rows = false;        // lib.rs:607-609: rows whose inputs are all 0.0 do not count
+};
+int net_zero_grad(Net* n, hipStream_t s);
+int net_accumulate(Net* n, const AccumArgs& a, hipStream_t s);
+int net_apply(Net* n, float lr, hipStream_t s);
+int net_reset_totals(Net* n, hipStream_t s);
+int net_read_totals(Net* n, hipStream_t s, double* loss_sum, double* live_rows);
+int net_vote_dev(Net* n, const float* x_dev, uint64_t rows, float threshold, unsigned long long* counts_dev, hipStream_t s);
+
+// uniform in [-0.5, 0.5) from a counter-based generator; used for weight initialisation
+float init_uniform(uint64_t seed, uint64_t index);
+
+}  // namespace sz

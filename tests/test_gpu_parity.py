@@ -1,0 +1,280 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle and the golden fixtures.
+
+Bars: window counts, vote counts and speaker lists exact; float32 features, probabilities
+and updated parameters within 1e-4 absolute of the oracle (the tolerance the task states),
+with the tighter values actually observed noted next to each check.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+CLIPS = ["noise", "tones", "voiced", "quiet", "fullscale", "short799", "exact800", "len1199", "len1200"]
+
+
+@pytest.fixture(scope="module")
+def sz():
+    import streamz_amd
+    return streamz_amd
+
+
+@pytest.fixture(scope="module")
+def po():
+    from oracle import pyoracle
+    return pyoracle
+
+
+@pytest.fixture(scope="module")
+def ext(sz):
+    return sz.FeatureExtractor()
+
+
+@pytest.fixture(scope="module")
+def oext(po):
+    return po.Extractor()
+
+
+def test_mel_filterbank_equals_oracle(ext, po):
+    np.testing.assert_allclose(ext.mel_filters(), po.mel_filterbank(), rtol=0, atol=1e-9)
+
+
+@pytest.mark.parametrize("clip", CLIPS)
+def test_extract_matches_oracle_and_golden(ext, oext, golden_features, clip):
+    pcm = golden_features[f"pcm_{clip}"]
+    got = ext.extract(pcm)
+    want = oext.extract(pcm, fft_mode=0)
+    assert got.shape == want.shape
+    np.testing.assert_allclose(got, want, atol=1e-4)
+    np.testing.assert_allclose(got, golden_features[f"feat_{clip}"], atol=1e-4)
+
+
+def test_extract_silence_and_clamps(ext, oext, golden_features):
+    # digital silence sits on the ln(1e-12) clamp (lib.rs:309): every frame equals the oracle's
+    pcm = golden_features["pcm_zeros"]
+    np.testing.assert_allclose(ext.extract(pcm), oext.extract(pcm, fft_mode=0), atol=1e-4)
+    # silence followed by a loud half: frames that are entirely silent or entirely loud and not
+    # within two frames of the boundary are held to 1e-4; the boundary frames mix clamped and
+    # unclamped energies through the deltas and are held to 5e-3
+    pcm = golden_features["pcm_silence_then_loud"]
+    got, want = ext.extract(pcm), oext.extract(pcm, fft_mode=0)
+    silent = np.array([not pcm[i * 400:i * 400 + 800].any() for i in range(len(got))])
+    near = np.convolve(silent.astype(int), np.ones(5, int), "same")
+    tight = (near == 0) | (near == 5)
+    np.testing.assert_allclose(got[tight], want[tight], atol=1e-4)
+    np.testing.assert_allclose(got, want, atol=5e-3)
+
+
+def test_extract_batch_ragged_files(ext, oext):
+    rng = np.random.default_rng(3)
+    lens = [0, 5, 799, 800, 2000, 48 * 400 + 400, 48 * 400 + 401, 49 * 400 + 400 + 6 * 400, 30000, 1201]
+    clips = [np.clip(np.round(0.2 * rng.standard_normal(n) * 32767), -32768, 32767).astype(np.int16) for n in lens]
+    outs = ext.extract_batch(clips)
+    for c, o in zip(clips, outs):
+        want = oext.extract(c, fft_mode=0)
+        assert o.shape == want.shape
+        if len(want):
+            np.testing.assert_allclose(o, want, atol=1e-4)
+
+
+def test_extract_long_clip_properties(ext, oext):
+    # 60 s clip (6 614 windows): spot-check windows against the oracle and check the
+    # size-independent properties of the z-score: zero mean, unit variance per frame
+    rng = np.random.default_rng(11)
+    t = np.arange(2_646_000) / 44100.0
+    x = 0.2 * np.sin(2 * np.pi * 150 * t) + 0.05 * np.sin(2 * np.pi * 1234 * t) + 0.01 * rng.standard_normal(t.size)
+    pcm = np.round(x * 32767).astype(np.int16)
+    got = ext.extract(pcm)
+    assert got.shape == (6614, 60)
+    np.testing.assert_allclose(got.mean(axis=1), 0, atol=2e-6)
+    np.testing.assert_allclose(got.var(axis=1), 1, atol=2e-5)
+    head = oext.extract(pcm[:400 * 60 + 800], fft_mode=1)
+    np.testing.assert_allclose(got[:58], head[:58], atol=1e-4)  # last 2 frames of `head` see its own end
+    tail = oext.extract(pcm[-(400 * 60 + 800):], fft_mode=1)
+    np.testing.assert_allclose(got[-58:], tail[-58:], atol=1e-4)
+
+
+@pytest.mark.parametrize("name", ["tiny", "mid", "wide"])
+def test_forward_and_train_batch_match_golden(sz, golden_net, name):
+    g = golden_net
+    dims = [int(v) for v in g[f"{name}_dims"]]
+    net = sz.SimpleNeuralNet(*dims, init=[g[f"{name}_p{i}"] for i in range(6)])
+    x = g[f"{name}_x"]
+    np.testing.assert_allclose(net.forward(x), g[f"{name}_probs"], atol=1e-5)
+    net.train_batch(x, g[f"{name}_target"], 0.05)
+    for i, p in enumerate(net.get_params()):
+        np.testing.assert_allclose(p, g[f"{name}_q{i}"].reshape(p.shape), atol=1e-5)
+
+
+@pytest.mark.parametrize("B", [1, 8, 1000])
+@pytest.mark.parametrize("C", [16, 3])
+def test_cli_sized_net_matches_oracle(sz, po, B, C):
+    rng = np.random.default_rng(100 + B + C)
+    dims = (60, 512, 256, C)
+    onet = po.Net(*dims)
+    params = [rng.uniform(-0.5, 0.5, s).astype(np.float32) for s in onet.shapes()]
+    params[1] = rng.uniform(-0.1, 0.1, 512).astype(np.float32)
+    onet.set_params(params)
+    net = sz.SimpleNeuralNet(*dims, init=params)
+    x = rng.standard_normal((B, 60)).astype(np.float32)
+    np.testing.assert_allclose(net.forward(x), onet.forward(x), atol=1e-4)
+    np.testing.assert_allclose(net.embed(x), onet.embed(x), atol=1e-4)
+    np.testing.assert_allclose(net.forward_embedding(x), onet.forward_embedding(x), atol=1e-3, rtol=1e-5)
+    target = np.zeros(C, np.float32)
+    target[1] = 1.0
+    net.train_batch(x, target, 0.01)
+    onet.train_batch(x, target, 0.01)
+    for p, q in zip(net.get_params(), onet.get_params()):
+        np.testing.assert_allclose(p, q, atol=1e-5)
+    np.testing.assert_allclose(net.forward(x), onet.forward(x), atol=1e-4)
+
+
+def test_train_equals_train_batch_of_one_and_changes_weights(sz, golden_net):
+    g = golden_net
+    dims = [int(v) for v in g["tiny_dims"]]
+    init = [g[f"tiny_p{i}"] for i in range(6)]
+    a, b = sz.SimpleNeuralNet(*dims, init=init), sz.SimpleNeuralNet(*dims, init=init)
+    a.train(g["tiny_x"][0], g["tiny_target"], 0.05)
+    b.train_batch(g["tiny_x"][:1], g["tiny_target"], 0.05)
+    for p, q in zip(a.get_params(), b.get_params()):
+        np.testing.assert_array_equal(p, q)
+    # the reference's own unit test (lib.rs:1831-1851)
+    assert any(not np.array_equal(p, init[i].reshape(p.shape)) for i, p in enumerate(a.get_params()))
+
+
+def test_empty_batch_is_a_no_op(sz, golden_net):
+    g = golden_net
+    dims = [int(v) for v in g["mid_dims"]]
+    init = [g[f"mid_p{i}"] for i in range(6)]
+    net = sz.SimpleNeuralNet(*dims, init=init)
+    net.train_batch(np.zeros((0, 60), np.float32), g["mid_target"], 0.05)
+    for i, p in enumerate(net.get_params()):
+        np.testing.assert_array_equal(p, init[i].reshape(p.shape))
+
+
+def test_pretrain_from_features_with_injected_rng(sz, po, golden_net):
+    g = golden_net
+    dims = [int(v) for v in g["loop_dims"]]
+    cls, ncls, epochs, batch = [int(v) for v in g["loop_cfg"]]
+    init = [g[f"loop_p{i}"] for i in range(6)]
+    net = sz.SimpleNeuralNet(*dims, init=init)
+    loss = sz.pretrain_from_features(net, g["loop_wins"], cls, ncls, epochs, 0.05, 0.2, batch,
+                                     perm=g["loop_perm"], keep=g["loop_keep"])
+    onet = po.Net(*dims)
+    onet.set_params(init)
+    oloss = onet.pretrain_from_features(g["loop_wins"], cls, ncls, epochs, 0.05, 0.2, batch,
+                                        perm=g["loop_perm"], keep=g["loop_keep"])
+    assert abs(loss - oloss) < 1e-5
+    assert abs(loss - float(g["loop_loss"])) < 2e-5
+    for p, q, i in zip(net.get_params(), onet.get_params(), range(6)):
+        np.testing.assert_allclose(p, q, atol=1e-5)
+        np.testing.assert_allclose(p, g[f"loop_q{i}"].reshape(p.shape), atol=2e-5)
+
+
+def test_pretrain_cli_schedule_small_file(sz, po):
+    # the CLI's schedule (batch 8, lr 0.01, dropout 0.2, main.rs:33-37, 658-666) on 100 windows
+    # for 3 epochs with the same injected streams on both sides
+    rng = np.random.default_rng(5)
+    dims = (60, 512, 256, 2)
+    onet = po.Net(*dims)
+    params = [rng.uniform(-0.5, 0.5, s).astype(np.float32) for s in onet.shapes()]
+    onet.set_params(params)
+    net = sz.SimpleNeuralNet(*dims, init=params)
+    wins = rng.standard_normal((100, 60)).astype(np.float32)
+    perm = np.stack([rng.permutation(100) for _ in range(3)]).astype(np.uint32)
+    keep = (rng.random((3, 100, 60)) >= 0.2).astype(np.uint8)
+    loss = sz.pretrain_from_features(net, wins, 1, 2, 3, 0.01, 0.2, 8, perm=perm, keep=keep)
+    oloss = onet.pretrain_from_features(wins, 1, 2, 3, 0.01, 0.2, 8, perm=perm, keep=keep)
+    assert abs(loss - oloss) < 1e-4 * max(1.0, abs(oloss))
+    for p, q in zip(net.get_params(), onet.get_params()):
+        np.testing.assert_allclose(p, q, atol=1e-4)
+
+
+def test_pretrain_no_windows_returns_zero(sz):
+    net = sz.SimpleNeuralNet(60, 8, 4, 2, seed=1)
+    before = net.get_flat()
+    assert sz.pretrain_from_features(net, np.zeros((0, 60), np.float32), 0, 2, 3, 0.01, 0.2, 8) == 0.0
+    np.testing.assert_array_equal(net.get_flat(), before)
+
+
+def test_identify_last_max_wins_and_stable_order(sz, golden_net):
+    g = golden_net
+    dims = [int(v) for v in g["ident_dims"]]
+    net = sz.SimpleNeuralNet(*dims, init=[g[f"ident_p{i}"] for i in range(6)])
+    ids, counts = sz.identify_from_features(net, g["ident_feats"], 0.3)
+    np.testing.assert_array_equal(counts, g["ident_counts"])
+    np.testing.assert_array_equal(ids, g["ident_ids"])
+
+
+def test_identify_speaker_list_end_to_end(sz, po, ext, oext):
+    rng = np.random.default_rng(9)
+    dims = (60, 512, 256, 5)
+    onet = po.Net(*dims)
+    params = [rng.uniform(-0.5, 0.5, s).astype(np.float32) for s in onet.shapes()]
+    onet.set_params(params)
+    net = sz.SimpleNeuralNet(*dims, init=params)
+    pcm = np.clip(np.round(0.3 * rng.standard_normal(44100 * 3) * 32767), -32768, 32767).astype(np.int16)
+    feats = oext.extract(pcm, fft_mode=0)
+    probs = onet.forward(feats)
+    top = np.sort(probs, axis=1)[:, -1]
+    thr = 0.6
+    # the comparison is exact unless a window's top probability sits within 1e-4 of the threshold
+    assert np.abs(top - thr).min() > 1e-4
+    assert sz.identify_speaker_list(net, pcm, thr, ext) == [int(v) for v in onet.identify_speaker_list(oext, pcm, thr)]
+    assert sz.identify_speaker_list(net, pcm[:700], thr, ext) == []
+
+
+def test_add_output_class_and_clone(sz):
+    rng = np.random.default_rng(2)
+    net = sz.SimpleNeuralNet(60, 16, 8, 2, seed=3)
+    before = net.get_params()
+    col = rng.uniform(-0.5, 0.5, 8).astype(np.float32)
+    twin = net.clone()
+    net.add_output_class(col)
+    after = net.get_params()
+    assert net.output_size() == 3 and twin.output_size() == 2
+    np.testing.assert_array_equal(after[4][:, :2], before[4])  # lib.rs:803-806
+    np.testing.assert_array_equal(after[4][:, 2], col)
+    np.testing.assert_array_equal(after[5], np.array([before[5][0], before[5][1], 0.0], np.float32))
+    for p, q in zip(twin.get_params(), before):
+        np.testing.assert_array_equal(p, q)
+    x = rng.standard_normal((4, 60)).astype(np.float32)
+    assert net.forward(x).shape == (4, 3)
+    np.testing.assert_allclose(net.forward(x).sum(axis=1), 1.0, atol=1e-6)
+
+
+def test_device_resident_epoch_matches_oracle_gradient(sz, po):
+    """zero_grad / accumulate / apply on device buffers equals the oracle's gradient sum and
+    update with per-row labels (the multi-file accumulate step)."""
+    import torch
+    rng = np.random.default_rng(21)
+    dims = (60, 512, 256, 16)
+    onet = po.Net(*dims)
+    params = [rng.uniform(-0.5, 0.5, s).astype(np.float32) for s in onet.shapes()]
+    onet.set_params(params)
+    net = sz.SimpleNeuralNet(*dims, init=params)
+    n = 3000
+    x = rng.standard_normal((n, 60)).astype(np.float32)
+    labels = rng.integers(0, 16, n).astype(np.int32)
+    dx = torch.from_numpy(x).cuda()
+    dl = torch.from_numpy(labels).cuda()
+    s = torch.cuda.current_stream().cuda_stream
+    net.zero_grad_dev(s)
+    net.accumulate_dev(dx.data_ptr(), dl.data_ptr(), 1700, stream=s)
+    net.accumulate_dev(dx[1700:].data_ptr(), dl[1700:].data_ptr(), n - 1700, stream=s)
+    torch.cuda.synchronize()
+    import ctypes
+    g = np.zeros(net.grad_len(), np.float32)
+    hip = ctypes.CDLL("libamdhip64.so")  # the gradient vector is library-owned device memory
+    assert hip.hipMemcpy(ctypes.c_void_p(g.ctypes.data), ctypes.c_void_p(net.grad_ptr()), g.nbytes, 2) == 0
+    want = onet.grad(x, labels=labels)
+    scale = np.abs(want).max()
+    np.testing.assert_allclose(g[:-2], want, atol=2e-5 * scale)
+    assert g[-1] == n
+    probs = onet.forward(x)
+    loss = -np.log(np.maximum(probs[np.arange(n), labels], 1e-12)).sum()
+    assert abs(g[-2] - loss) < 1e-4 * loss
+    net.apply_grad_dev(0.5, s)
+    torch.cuda.synchronize()
+    onet.apply(want, 0.5 / n)
+    for p, q in zip(net.get_params(), onet.get_params()):
+        np.testing.assert_allclose(p, q, atol=1e-5)
