@@ -3,6 +3,7 @@
 train_from_feature_map, identify_speaker_list, load_cached_features."""
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -94,6 +95,14 @@ def lib():
     if _lib is None:
         if not os.path.exists(_SO):
             raise StreamzError(-2, f"{_SO} is not built; run `python -c 'import __graft_entry__ as g; g.build()'`")
+        # PyTorch wheels bundle their own HIP/HSA runtime.  A process may hold only one: if
+        # torch is importable, load it first so that this library binds to the same
+        # libamdhip64.so.7 instead of bringing in a second copy (torch then finds no GPU).
+        if "torch" not in sys.modules:
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
         L = C.CDLL(_SO)
         for name, (res, args) in _SIGS.items():
             fn = getattr(L, name)
