@@ -1,0 +1,269 @@
+#!/usr/bin/env python3
+"""Headline benchmark: feature-windows/sec (extract + train) on synthetic 44.1 kHz PCM.
+
+One "step" = one pass of the hot path over the rank's clips, everything device-resident:
+  extract   PCM (int16, already in HBM) -> 60 z-scored MFCC+delta+delta-delta features per window
+  train     one epoch over all windows: forward, softmax/cross-entropy, backward, gradients summed
+            on the device, [all-reduce of the 0.67 MB gradient vector across ranks,] one SGD update
+windows/sec = windows of all ranks / (t_extract + t_epoch), max over ranks, K timed steps.
+
+Default workload = BASELINE.json configs[1]: 1 000 clips x 60 s, 16 speakers, net 60-512-256-16,
+per GPU (weak scaling: every rank holds its own 1 000 clips, no data-path collective except the
+per-epoch gradient all-reduce).
+
+Launch:  python bench.py --gpus 1 --steps 3 --warmup 1
+         python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch  # before streamz_amd: one HIP runtime per process
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import streamz_amd as sz  # noqa: E402
+
+SR = 44100
+PEAK_F32_MATRIX_TFLOPS = 157.3   # MI355X dense f32 MFMA / vector peak
+PEAK_HBM_GBPS = 8000.0
+
+
+class _DevView:
+    """Zero-copy torch view of library-owned device memory."""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (ptr, False), "version": 2}
+
+
+def synth_clips(n_clips, seconds, speakers, device, first_clip=0):
+    """Speaker s = 4 harmonics of f0 = 90 + 12 s Hz + white noise at -30 dB, about 0.25 FS."""
+    n = int(seconds * SR)
+    n_al = (n + 7) // 8 * 8
+    pcm = torch.zeros(n_clips * n_al, dtype=torch.int16, device=device)
+    t = torch.arange(n, device=device, dtype=torch.float64) / SR
+    amps = [1.0, 0.6, 0.4, 0.25]
+    gen = torch.Generator(device=device)
+    for i in range(n_clips):
+        clip = first_clip + i
+        s = clip % speakers
+        f0 = 90.0 + 12.0 * s
+        x = torch.zeros(n, device=device, dtype=torch.float64)
+        for h, a in enumerate(amps):
+            a_s = a * (1.0 + 0.3 * np.sin(1.7 * s + h))  # per-speaker formant-ish pattern
+            x += a_s * torch.sin(2 * np.pi * f0 * (h + 1) * t + 0.5 * h)
+        x *= 0.25 / float(sum(amps))
+        gen.manual_seed(1234 + clip)
+        x += 0.25 * 10 ** (-30 / 20) * torch.randn(n, device=device, dtype=torch.float32, generator=gen).double()
+        pcm[i * n_al:i * n_al + n] = torch.clamp(torch.round(x * 32767.0), -32768, 32767).to(torch.int16)
+    offsets = np.arange(n_clips, dtype=np.uint64) * n_al
+    lengths = np.full(n_clips, n, np.uint64)
+    return pcm, offsets, lengths
+
+
+def cpu_baseline(speakers, hidden, seconds):
+    """The CPU restatement (oracle/) on a bounded sample: extraction with OpenMP over clips as
+    main.rs:500-508 does, training serial at batch 8 as lib.rs:599-622 does."""
+    from oracle import pyoracle as po
+    threads = min(16, os.cpu_count() or 1)
+    os.environ["OMP_NUM_THREADS"] = str(threads)
+    n_clips = 8
+    pcm, off, ln = synth_clips(n_clips, seconds, speakers, "cpu")
+    pcm = pcm.numpy()
+    ext = po.Extractor()
+    ext.extract_files(pcm[: int(ln[0])], off[:1], ln[:1], fft_mode=1)  # warm tables / threads
+    t0 = time.perf_counter()
+    feats, woff, nw = ext.extract_files(pcm, off, ln, fft_mode=1)
+    t_ext = time.perf_counter() - t0
+    n_ext = int(nw.sum())
+    net = po.Net(60, hidden[0], hidden[1], speakers)
+    rng = np.random.default_rng(0)
+    net.set_params([rng.uniform(-0.5, 0.5, s).astype(np.float32) if len(s) == 2 else np.zeros(s, np.float32)
+                    for s in net.shapes()])
+    n_train = 3000
+    t0 = time.perf_counter()
+    net.pretrain_from_features(feats[:n_train], 1, speakers, 1, 0.01, 0.2, 8)
+    t_tr = time.perf_counter() - t0
+    per_win = t_ext / n_ext + t_tr / n_train
+    return {
+        "value": 1.0 / per_win,
+        "unit": "windows/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": (f"extract: {n_clips} clips x {seconds:g} s = {n_ext} windows on {threads} OpenMP threads "
+                   f"({n_ext / t_ext:.0f} windows/s); train: one epoch of {n_train} windows at batch 8, dropout 0.2, "
+                   f"serial on 1 core as the reference does ({n_train / t_tr:.0f} windows/s); "
+                   "value = 1 / (s_per_window_extract + s_per_window_train)"),
+        "extract_windows_per_s": n_ext / t_ext,
+        "train_windows_per_s": n_train / t_tr,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--clips", type=int, default=1000, help="clips per GPU")
+    ap.add_argument("--seconds", type=float, default=60.0)
+    ap.add_argument("--speakers", type=int, default=16)
+    ap.add_argument("--hidden1", type=int, default=512)
+    ap.add_argument("--hidden2", type=int, default=256)
+    ap.add_argument("--lr", type=float, default=0.01)
+    ap.add_argument("--dropout", type=float, default=0.2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        dist = None
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    sz.lib().szh_init(dev.index)
+
+    # ---- synthetic, device-resident inputs
+    pcm, offsets, lengths = synth_clips(args.clips, args.seconds, args.speakers, dev, first_clip=rank * args.clips)
+    ext = sz.FeatureExtractor()
+    plan = sz.Plan(ext, offsets, lengths)
+    n_win = plan.total_windows
+    feats = torch.empty((n_win, 60), dtype=torch.float32, device=dev)
+    per_file = np.diff(plan.window_offsets).astype(np.int64)
+    clip_speaker = (np.arange(args.clips) + rank * args.clips) % args.speakers
+    labels = torch.from_numpy(np.repeat(clip_speaker, per_file).astype(np.int32)).to(dev)
+    net = sz.SimpleNeuralNet(60, args.hidden1, args.hidden2, args.speakers, seed=42)  # same init on every rank
+    grad = torch.as_tensor(_DevView(net.grad_ptr(), net.grad_len()), device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+
+    def step(k, record=False):
+        if record:
+            ev[0].record()
+        plan.run(pcm.data_ptr(), feats.data_ptr(), stream)
+        if record:
+            ev[1].record()
+        net.zero_grad_dev(stream)
+        net.accumulate_dev(feats.data_ptr(), labels.data_ptr(), n_win, args.dropout, 1000 + k, stream)
+        if dist is not None:
+            dist.all_reduce(grad)  # sums gradients, loss and live-row count over ranks
+        net.apply_grad_dev(args.lr, stream)
+        if record:
+            ev[2].record()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for k in range(args.warmup):
+        step(k)
+    barrier()
+    if not args.no_profile:
+        sz.profile_enable(True)
+        sz.profile_report()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(args.warmup + k, record=(k == args.steps - 1))
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = {} if args.no_profile else sz.profile_report()
+    sz.profile_enable(False)
+    t_ext_ms = ev[0].elapsed_time(ev[1])
+    t_train_ms = ev[1].elapsed_time(ev[2])
+    loss_sum, live = [float(v) for v in grad[-2:].tolist()]
+
+    if dist is not None:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    ms_per_step = 1000.0 * elapsed / args.steps
+    value = world * n_win * args.steps / elapsed
+
+    # ---- roofline of the dominant kernel, from the event pairs recorded during the timed steps
+    C, H1, H2 = args.speakers, args.hidden1, args.hidden2
+    rows_per_launch = 32768  # rows of one launch (the library's chunk); the last chunk is shorter
+    flops_per_row = {"fwd1": 2 * 60 * H1, "fwd2": 2 * H1 * H2, "fwd3": 2 * H2 * C, "delta2": 2 * C * H2,
+                     "delta1": 2 * H2 * H1, "dw3": 2 * H2 * C, "dw2": 2 * H1 * H2, "dw1": 2 * 60 * H1}
+    roofline = None
+    kernels = {}
+    if prof:
+        for tag, (cnt, ms) in prof.items():
+            kernels[tag] = {"launches": cnt, "total_ms": round(ms, 3), "avg_us": round(1000.0 * ms / cnt, 2)}
+        dom = max(prof, key=lambda k: prof[k][1])
+        cnt, ms = prof[dom]
+        if dom in flops_per_row:
+            # algorithmic flops of all launches of this kernel in the timed steps / their total duration
+            total_flops = flops_per_row[dom] * n_win * args.steps
+            achieved = total_flops / (ms * 1e-3) / 1e12
+            roofline = {"kernel": dom, "bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MATRIX_TFLOPS,
+                        "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MATRIX_TFLOPS, "traffic": None,
+                        "avg_launch_us": 1000.0 * ms / cnt,
+                        "flops_per_launch": flops_per_row[dom] * min(rows_per_launch, n_win)}
+        else:
+            total_bytes = 1040.0 * n_win * args.steps
+            achieved = total_bytes / (ms * 1e-3) / 1e9
+            roofline = {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                        "frac": achieved / PEAK_HBM_GBPS, "traffic": None, "avg_launch_us": 1000.0 * ms / cnt}
+        ext_ms = sum(prof[t][1] for t in ("mfcc_base", "finish") if t in prof)
+        if ext_ms > 0:
+            ext_gbps = 1040.0 * n_win * args.steps / (ext_ms * 1e-3) / 1e9
+            kernels["extract_total"] = {"algorithmic_GBps": round(ext_gbps, 1), "frac_of_hbm_peak": ext_gbps / PEAK_HBM_GBPS,
+                                        "windows_per_s": n_win * args.steps / (ext_ms * 1e-3)}
+
+    out = {
+        "metric": "feature-windows/sec (extract+train)",
+        "value": value,
+        "unit": "windows/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": (f"configs[1]: {args.clips} x {args.seconds:g} s synthetic 44.1 kHz mono clips per GPU, "
+                         f"{args.speakers} speakers, net 60-{H1}-{H2}-{C}"),
+            "windows_per_gpu": n_win,
+            "batch": "one optimiser step per epoch over all windows (gradients summed on device"
+                     + (", RCCL all-reduce across ranks)" if world > 1 else ")"),
+            "epochs_per_step": 1,
+            "dropout": args.dropout,
+            "lr": args.lr,
+            "parallelism": f"files sharded over {world} GPU(s)",
+        },
+        "breakdown_ms": {"extract": t_ext_ms, "train_epoch": t_train_ms},
+        "extract_windows_per_s": n_win / (t_ext_ms * 1e-3),
+        "train_windows_per_s": n_win / (t_train_ms * 1e-3),
+        "mean_loss_last_step": loss_sum / live if live > 0 else None,
+        "roofline": roofline,
+        "kernels": kernels,
+    }
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args.speakers, (H1, H2), args.seconds)
+    print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

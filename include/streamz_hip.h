@@ -218,6 +218,16 @@ int szh_load_cached_features(const char *path, szh_extractor *ext, float **feats
  * *pcm is malloc'd mono int16; release with szh_free. */
 int szh_wav_read(const char *path, int16_t **pcm, uint64_t *n_samples);
 
+/* ---- measurement ----------------------------------------------------------------------- */
+/* No counterpart in the reference.  When enabled, every kernel launch of the extraction and
+ * network paths is bracketed by a HIP event pair on its launch stream.  szh_profile_report
+ * synchronises the device, writes one line "tag launches total_ms" per kernel tag seen since
+ * the previous report into buf (NUL-terminated, truncated to capacity) and returns the full
+ * text length.  Tags: mfcc_base, finish, prep, fwd1, fwd2, fwd3, softmax, delta2, delta1,
+ * dw3, dw2, dw1, bias, reduce, apply, vote. */
+int szh_profile_enable(int on);
+int64_t szh_profile_report(char *buf, uint64_t capacity);
+
 #ifdef __cplusplus
 }
 #endif

@@ -81,6 +81,8 @@ _SIGS = {
     "szh_net_load": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
     "szh_load_cached_features": (C.c_int, [C.c_char_p, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
     "szh_wav_read": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
+    "szh_profile_enable": (C.c_int, [C.c_int]),
+    "szh_profile_report": (C.c_int64, [C.c_void_p, C.c_uint64]),
 }
 
 
@@ -425,3 +427,20 @@ def wav_read(path):
     finally:
         lib().szh_free(ptr)
     return arr
+
+
+def profile_enable(on=True):
+    _check(lib().szh_profile_enable(1 if on else 0))
+
+
+def profile_report():
+    """{tag: (launches, total_ms)} of the kernels launched since the previous report."""
+    buf = C.create_string_buffer(1 << 16)
+    n = lib().szh_profile_report(buf, len(buf))
+    if n < 0:
+        _check(int(n))
+    out = {}
+    for line in buf.value.decode().splitlines():
+        tag, cnt, ms = line.split()
+        out[tag] = (int(cnt), float(ms))
+    return out

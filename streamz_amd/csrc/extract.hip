@@ -10,6 +10,7 @@
 //                     z-score (lib.rs:212-228, 321-342); streams 80 B in, 240 B out per window.
 #include "extract_phases.h"
 #include "internal.h"
+#include "prof.h"
 #include "streamz_hip.h"
 
 namespace sz {
@@ -250,12 +251,18 @@ int plan_run(Plan* p, const int16_t* pcm_dev, float* feats_dev, hipStream_t stre
     }
     const uint32_t wave_jobs = (p->n_segs + kBaseWaves - 1) / kBaseWaves;
     const uint32_t grid_a = wave_jobs < 256u * 2u * 8u ? wave_jobs : 256u * 2u * 8u;
-    hipLaunchKernelGGL(mfcc_base_kernel, dim3(grid_a), dim3(kBaseThreads), kBaseLdsBytes, stream, pcm_dev,
-                       p->d_segs, p->n_segs, p->ext->dev, p->d_base);
+    {
+        ProfScope prof("mfcc_base", stream);
+        hipLaunchKernelGGL(mfcc_base_kernel, dim3(grid_a), dim3(kBaseThreads), kBaseLdsBytes, stream, pcm_dev,
+                           p->d_segs, p->n_segs, p->ext->dev, p->d_base);
+    }
     SZ_HIP(hipGetLastError());
     const uint32_t grid_b = p->n_segs < 256u * 32u ? p->n_segs : 256u * 32u;
-    hipLaunchKernelGGL(finish_kernel, dim3(grid_b), dim3(kFinishThreads), 0, stream, p->d_base, p->d_segs,
-                       p->n_segs, feats_dev);
+    {
+        ProfScope prof("finish", stream);
+        hipLaunchKernelGGL(finish_kernel, dim3(grid_b), dim3(kFinishThreads), 0, stream, p->d_base, p->d_segs,
+                           p->n_segs, feats_dev);
+    }
     SZ_HIP(hipGetLastError());
     return SZH_OK;
 }

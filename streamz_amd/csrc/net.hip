@@ -11,6 +11,7 @@
 #include <new>
 
 #include "internal.h"
+#include "prof.h"
 #include "streamz_hip.h"
 
 namespace sz {
@@ -106,7 +107,8 @@ __device__ __forceinline__ void stash_krows(float* S, const Frag4 (&f)[2])
     }
 }
 
-template <int AM, int BMd, int EPI>
+// TAG only separates instantiations, so that each call site is its own kernel in a profile.
+template <int AM, int BMd, int EPI, int TAG>
 __global__ __launch_bounds__(kGemmThreads) void gemm_kernel(GemmArgs g)
 {
     __shared__ __attribute__((aligned(16))) float As[BK * LDT];
@@ -180,14 +182,20 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_kernel(GemmArgs g)
 
 inline int vec_ok(const void* p, int ld) { return (((uintptr_t)p & 15) == 0 && (ld & 3) == 0) ? 1 : 0; }
 
-template <int AM, int BMd, int EPI>
+enum GemmTag { T_FWD1 = 0, T_FWD2, T_FWD3, T_DELTA2, T_DELTA1, T_DW3, T_DW2, T_DW1 };
+const char* const kGemmTagName[] = {"fwd1", "fwd2", "fwd3", "delta2", "delta1", "dw3", "dw2", "dw1"};
+
+template <int AM, int BMd, int EPI, int TAG>
 int launch_gemm(GemmArgs g, int splits, hipStream_t s)
 {
     if (g.M <= 0 || g.N <= 0) return SZH_OK;
     g.a_vec = vec_ok(g.A, g.lda);
     g.b_vec = vec_ok(g.B, g.ldb);
     dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, splits);
-    hipLaunchKernelGGL((gemm_kernel<AM, BMd, EPI>), grid, dim3(kGemmThreads), 0, s, g);
+    {
+        ProfScope prof(kGemmTagName[TAG], s);
+        hipLaunchKernelGGL((gemm_kernel<AM, BMd, EPI, TAG>), grid, dim3(kGemmThreads), 0, s, g);
+    }
     SZ_HIP(hipGetLastError());
     return SZH_OK;
 }
@@ -397,13 +405,13 @@ int forward_hidden(Net* n, const float* x, uint64_t rows, bool relu2, hipStream_
     GemmArgs g{};
     g.A = x; g.lda = n->in; g.B = P + n->off_w1(); g.ldb = n->h1; g.C = w.h1; g.ldc = n->h1;
     g.M = (int)rows; g.N = n->h1; g.K = n->in; g.k_chunk = n->in; g.bias = P + n->off_b1();
-    int rc = launch_gemm<A_ROWS, B_KROWS, EPI_BIAS_RELU>(g, 1, s);
+    int rc = launch_gemm<A_ROWS, B_KROWS, EPI_BIAS_RELU, T_FWD1>(g, 1, s);
     if (rc) return rc;
     g = GemmArgs{};
     g.A = w.h1; g.lda = n->h1; g.B = P + n->off_w2(); g.ldb = n->h2; g.C = w.h2; g.ldc = n->h2;
     g.M = (int)rows; g.N = n->h2; g.K = n->h1; g.k_chunk = n->h1; g.bias = P + n->off_b2();
-    return relu2 ? launch_gemm<A_ROWS, B_KROWS, EPI_BIAS_RELU>(g, 1, s)
-                 : launch_gemm<A_ROWS, B_KROWS, EPI_BIAS_TANH>(g, 1, s);
+    return relu2 ? launch_gemm<A_ROWS, B_KROWS, EPI_BIAS_RELU, T_FWD2>(g, 1, s)
+                 : launch_gemm<A_ROWS, B_KROWS, EPI_BIAS_TANH, T_FWD2>(g, 1, s);
 }
 
 int forward_logits(Net* n, uint64_t rows, float* out, hipStream_t s)
@@ -413,9 +421,10 @@ int forward_logits(Net* n, uint64_t rows, float* out, hipStream_t s)
     GemmArgs g{};
     g.A = w.h2; g.lda = n->h2; g.B = P + n->off_w3(); g.ldb = n->out; g.C = out; g.ldc = n->out;
     g.M = (int)rows; g.N = n->out; g.K = n->h2; g.k_chunk = n->h2; g.bias = P + n->off_b3();
-    return launch_gemm<A_ROWS, B_KROWS, EPI_BIAS>(g, 1, s);
+    return launch_gemm<A_ROWS, B_KROWS, EPI_BIAS, T_FWD3>(g, 1, s);
 }
 
+template <int TAG>
 int grad_gemm(Net* n, const float* A, int lda, const float* B, int ldb, int M, int N, uint64_t rows, float* grad,
               hipStream_t s)
 {
@@ -429,11 +438,14 @@ int grad_gemm(Net* n, const float* A, int lda, const float* B, int ldb, int M, i
     GemmArgs g{};
     g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = w.slab; g.ldc = N;
     g.M = M; g.N = N; g.K = (int)rows; g.k_chunk = k_chunk;
-    int rc = launch_gemm<A_KROWS, B_KROWS, EPI_SLAB>(g, splits, s);
+    int rc = launch_gemm<A_KROWS, B_KROWS, EPI_SLAB, TAG>(g, splits, s);
     if (rc) return rc;
     const uint64_t len = (uint64_t)M * N;
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, s, w.slab, splits, len,
-                       grad);
+    {
+        ProfScope prof("reduce", s);
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, s, w.slab, splits,
+                           len, grad);
+    }
     SZ_HIP(hipGetLastError());
     return SZH_OK;
 }
@@ -446,11 +458,13 @@ int grad_bias(Net* n, const float* D, int cols, uint64_t rows, float* grad, hipS
     if (splits < 1) splits = 1;
     const int rps = (int)((rows + splits - 1) / splits);
     splits = (int)((rows + rps - 1) / rps);
-    hipLaunchKernelGGL(colsum_kernel, dim3((cols + 63) / 64, splits), dim3(256), 0, s, D, rows, cols, cols, rps,
-                       w.slab);
-    SZ_HIP(hipGetLastError());
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3((cols + 255) / 256), dim3(256), 0, s, w.slab, splits, (uint64_t)cols,
-                       grad);
+    {
+        ProfScope prof("bias", s);
+        hipLaunchKernelGGL(colsum_kernel, dim3((cols + 63) / 64, splits), dim3(256), 0, s, D, rows, cols, cols, rps,
+                           w.slab);
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3((cols + 255) / 256), dim3(256), 0, s, w.slab, splits,
+                           (uint64_t)cols, grad);
+    }
     SZ_HIP(hipGetLastError());
     return SZH_OK;
 }
@@ -607,41 +621,47 @@ int net_accumulate(Net* n, const AccumArgs& a, hipStream_t s)
     for (uint64_t r0 = 0; r0 < a.rows; r0 += kChunkRows) {
         const uint64_t R = std::min<uint64_t>(kChunkRows, a.rows - r0);
         // gather / dropout / live flags
-        hipLaunchKernelGGL(prep_rows_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s,
+        {
+            ProfScope prof("prep", s);
+            hipLaunchKernelGGL(prep_rows_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s,
                            a.perm_dev ? a.x_dev : a.x_dev + r0 * n->in, a.perm_dev ? a.perm_dev + r0 : nullptr,
                            a.keep_dev ? a.keep_dev + r0 * n->in : nullptr, a.dropout, a.seed, a.row_counter0 + r0, R,
                            (int)n->in, a.skip_zero_rows ? 1 : 0, w.xd, w.live);
+        }
         SZ_HIP(hipGetLastError());
         rc = forward_hidden(n, w.xd, R, false, s);
         if (rc) return rc;
         rc = forward_logits(n, R, w.p, s);
         if (rc) return rc;
-        hipLaunchKernelGGL(softmax_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s, w.p, R, (int)n->out, 1,
-                           a.target_dev, a.labels_dev ? a.labels_dev + r0 : nullptr, (const uint8_t*)w.live,
-                           n->d_stats);
+        {
+            ProfScope prof("softmax", s);
+            hipLaunchKernelGGL(softmax_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s, w.p, R, (int)n->out,
+                               1, a.target_dev, a.labels_dev ? a.labels_dev + r0 : nullptr, (const uint8_t*)w.live,
+                               n->d_stats);
+        }
         SZ_HIP(hipGetLastError());
         // delta2 = (delta3 . w3^T) * (1 - h2^2)
         GemmArgs g{};
         g.A = w.p; g.lda = n->out; g.B = P + n->off_w3(); g.ldb = n->out; g.C = w.d2; g.ldc = n->h2;
         g.M = (int)R; g.N = n->h2; g.K = n->out; g.k_chunk = n->out; g.aux = w.h2; g.ldaux = n->h2;
-        rc = launch_gemm<A_ROWS, B_ROWS, EPI_MUL_DTANH>(g, 1, s);
+        rc = launch_gemm<A_ROWS, B_ROWS, EPI_MUL_DTANH, T_DELTA2>(g, 1, s);
         if (rc) return rc;
         // delta1 = (delta2 . w2^T) * [h1 > 0]
         g = GemmArgs{};
         g.A = w.d2; g.lda = n->h2; g.B = P + n->off_w2(); g.ldb = n->h2; g.C = w.d1; g.ldc = n->h1;
         g.M = (int)R; g.N = n->h1; g.K = n->h2; g.k_chunk = n->h2; g.aux = w.h1; g.ldaux = n->h1;
-        rc = launch_gemm<A_ROWS, B_ROWS, EPI_MUL_DRELU>(g, 1, s);
+        rc = launch_gemm<A_ROWS, B_ROWS, EPI_MUL_DRELU, T_DELTA1>(g, 1, s);
         if (rc) return rc;
         // weight gradients: contractions over the rows
-        rc = grad_gemm(n, w.h2, n->h2, w.p, n->out, n->h2, n->out, R, G + n->off_w3(), s);
+        rc = grad_gemm<T_DW3>(n, w.h2, n->h2, w.p, n->out, n->h2, n->out, R, G + n->off_w3(), s);
         if (rc) return rc;
         rc = grad_bias(n, w.p, n->out, R, G + n->off_b3(), s);
         if (rc) return rc;
-        rc = grad_gemm(n, w.h1, n->h1, w.d2, n->h2, n->h1, n->h2, R, G + n->off_w2(), s);
+        rc = grad_gemm<T_DW2>(n, w.h1, n->h1, w.d2, n->h2, n->h1, n->h2, R, G + n->off_w2(), s);
         if (rc) return rc;
         rc = grad_bias(n, w.d2, n->h2, R, G + n->off_b2(), s);
         if (rc) return rc;
-        rc = grad_gemm(n, w.xd, n->in, w.d1, n->h1, n->in, n->h1, R, G + n->off_w1(), s);
+        rc = grad_gemm<T_DW1>(n, w.xd, n->in, w.d1, n->h1, n->in, n->h1, R, G + n->off_w1(), s);
         if (rc) return rc;
         rc = grad_bias(n, w.d1, n->h1, R, G + n->off_b1(), s);
         if (rc) return rc;
@@ -655,8 +675,11 @@ int net_apply(Net* n, float lr, hipStream_t s)
 {
     const uint64_t np = n->param_count();
     if (np == 0) return SZH_OK;
-    hipLaunchKernelGGL(apply_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, n->d_params, n->d_grad, np,
-                       lr);
+    {
+        ProfScope prof("apply", s);
+        hipLaunchKernelGGL(apply_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, n->d_params, n->d_grad,
+                           np, lr);
+    }
     SZ_HIP(hipGetLastError());
     return SZH_OK;
 }
