@@ -1,0 +1,326 @@
+// StreamZ command-line host: the training flow of the reference binary
+// (streamz-rs/src/main.rs:326-892) for 16-bit PCM WAV input at 44.1 kHz, over libstreamz_hip.so.
+//
+//   train_files.txt  one "path[,label]" per line (main.rs:41-64); rewritten at exit with the
+//                    final labels (main.rs:870-875)
+//   target_files.txt labelled lines only, written at exit (main.rs:81-89, 876)
+//   model.npz        loaded when present (then the 100-epoch initial pass is skipped,
+//                    main.rs:652), written at exit (main.rs:856)
+//   feature_cache/   written by compute_speaker_embeddings -> load_cached_features
+//
+// Not handled here (outside the accelerated path): MP3 input and cache/*.wav, resampling,
+// --eval, --encode / --decode / --checksum.  The reference processes the second pass under a
+// rayon par_iter whose iterations serialise on the net's write lock in an unspecified order;
+// here the files are taken in list order, one valid schedule of that loop.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <set>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include <sys/stat.h>
+
+#include "streamz.hpp"
+
+using namespace streamz;
+
+namespace {
+
+const char* MODEL_PATH = "model.npz";              // main.rs:21
+const char* TRAIN_FILE_LIST = "train_files.txt";   // main.rs:22
+const char* TARGET_FILE_LIST = "target_files.txt"; // main.rs:23
+const float DEFAULT_CONF_THRESHOLD = 0.8f;         // main.rs:27
+const float DEFAULT_BURN_IN_FRAC = 0.2f;           // main.rs:30
+const size_t TRAIN_EPOCHS = 100;                   // main.rs:33
+const float DROPOUT_PROB = DEFAULT_DROPOUT;        // main.rs:35
+const size_t BATCH_SIZE = 8;                       // main.rs:37
+
+struct Entry { std::string path; bool labelled; size_t cls; };
+
+std::string trim(const std::string& s)
+{
+    size_t a = 0, b = s.size();
+    while (a < b && std::isspace((unsigned char)s[a])) ++a;
+    while (b > a && std::isspace((unsigned char)s[b - 1])) --b;
+    return s.substr(a, b - a);
+}
+
+bool parse_usize(const std::string& s, size_t& out)
+{
+    if (s.empty()) return false;
+    size_t i = 0;
+    if (s[0] == '+') i = 1;  // Rust's usize::from_str accepts a leading '+'
+    if (i >= s.size()) return false;
+    size_t v = 0;
+    for (; i < s.size(); ++i) {
+        if (s[i] < '0' || s[i] > '9') return false;
+        v = v * 10 + (size_t)(s[i] - '0');
+    }
+    out = v;
+    return true;
+}
+
+// load_train_files, main.rs:41-64
+std::vector<Entry> load_train_files(const char* path)
+{
+    std::vector<Entry> files;
+    std::ifstream in(path);
+    if (!in) return files;
+    std::string line;
+    while (std::getline(in, line)) {
+        if (!line.empty() && line.back() == '\r') line.pop_back();
+        std::vector<std::string> parts;
+        size_t pos = 0;
+        while (true) {
+            const size_t c = line.find(',', pos);
+            parts.push_back(line.substr(pos, c == std::string::npos ? std::string::npos : c - pos));
+            if (c == std::string::npos) break;
+            pos = c + 1;
+        }
+        const std::string p = trim(parts[0]);
+        if (p.empty()) continue;
+        Entry e{p, false, 0};
+        if (parts.size() > 1) {
+            size_t cls;
+            if (parse_usize(trim(parts[1]), cls)) { e.labelled = true; e.cls = cls; }
+        }
+        files.push_back(e);
+    }
+    return files;
+}
+
+// write_train_files, main.rs:66-79 / write_target_files, main.rs:81-89
+void write_list(const char* path, const std::vector<Entry>& files, bool labelled_only)
+{
+    std::ofstream out(path);
+    if (!out) return;
+    for (const Entry& e : files) {
+        if (e.labelled) out << e.path << "," << e.cls << "\n";
+        else if (!labelled_only) out << e.path << "\n";
+    }
+}
+
+// count_speakers, main.rs:129-135
+size_t count_speakers(const std::vector<Entry>& files)
+{
+    std::set<size_t> s;
+    for (const Entry& e : files)
+        if (e.labelled) s.insert(e.cls);
+    return s.size();
+}
+
+bool exists(const char* p)
+{
+    struct stat st;
+    return ::stat(p, &st) == 0;
+}
+
+int find_arg(int argc, char** argv, const char* name)
+{
+    for (int i = 1; i < argc; ++i)
+        if (std::strcmp(argv[i], name) == 0) return i;
+    return -1;
+}
+
+// print_embedding_quality, main.rs:243-279
+void print_embedding_quality(const SimpleNeuralNet& net, const FeatureExtractor& ext)
+{
+    std::vector<SimpleNeuralNet::Embedding> e = net.embeddings();
+    if (!e.empty()) std::printf("Saved embeddings found in model.npz:\n");
+    else e = compute_speaker_embeddings(net, ext);
+    if (e.empty()) { std::printf("No embeddings available to evaluate\n"); return; }
+    float sum = 0.0f;
+    for (size_t i = 0; i < e.size(); ++i) {
+        sum += e[i].second.first;
+        std::printf("Speaker %zu: mean similarity %.4f, std dev %.4f\n", i, e[i].second.first, e[i].second.second);
+    }
+    std::printf("Average mean similarity: %.4f\n", sum / (float)e.size());
+}
+
+}  // namespace
+
+int main(int argc, char** argv)
+{
+    try {
+        float conf_threshold = DEFAULT_CONF_THRESHOLD;
+        bool have_burn = false;
+        size_t burn_in_limit = 0;
+        int idx;
+        uint64_t seed = 0x5EEDull;
+        if ((idx = find_arg(argc, argv, "--seed")) >= 0 && idx + 1 < argc) seed = std::strtoull(argv[idx + 1], nullptr, 10);
+        if ((idx = find_arg(argc, argv, "--device")) >= 0 && idx + 1 < argc) check(szh_init(std::atoi(argv[idx + 1])));
+        for (const char* flag : {"--eval", "--encode", "--decode", "--checksum"})
+            if (find_arg(argc, argv, flag) >= 0) {
+                std::fprintf(stderr, "%s is not part of the accelerated path and is not handled by this binary\n", flag);
+                return 2;
+            }
+        FeatureExtractor extractor;
+        if (find_arg(argc, argv, "--check-embeddings") >= 0) {  // main.rs:357-366
+            try {
+                SimpleNeuralNet net = SimpleNeuralNet::load(MODEL_PATH);
+                std::printf("Loaded %s for embedding check\n", MODEL_PATH);
+                print_embedding_quality(net, extractor);
+            } catch (const Error& e) {
+                std::fprintf(stderr, "Failed to load model from %s: %s\n", MODEL_PATH, e.what());
+            }
+            return 0;
+        }
+        if ((idx = find_arg(argc, argv, "--threshold")) >= 0) {  // main.rs:367-382
+            if (idx + 1 < argc) {
+                char* end = nullptr;
+                const float v = std::strtof(argv[idx + 1], &end);
+                if (end && *end == 0 && end != argv[idx + 1]) conf_threshold = v;
+                else std::fprintf(stderr, "Invalid value for --threshold '%s', using default %g\n", argv[idx + 1], DEFAULT_CONF_THRESHOLD);
+            } else {
+                std::fprintf(stderr, "Missing value for --threshold, using default %g\n", DEFAULT_CONF_THRESHOLD);
+            }
+        }
+        (void)conf_threshold;  // only the --eval mode of the reference reads it
+        if ((idx = find_arg(argc, argv, "--burn-in-limit")) >= 0) {  // main.rs:398-410
+            size_t v;
+            if (idx + 1 < argc && parse_usize(argv[idx + 1], v)) { have_burn = true; burn_in_limit = v; }
+            else std::fprintf(stderr, "Invalid or missing value for --burn-in-limit, using automatic setting\n");
+        }
+
+        std::vector<Entry> train_files = load_train_files(TRAIN_FILE_LIST);  // main.rs:471-475
+        if (train_files.empty()) {
+            std::fprintf(stderr, "%s is empty\n", TRAIN_FILE_LIST);
+            return 0;
+        }
+        const std::vector<Entry> original = train_files;
+
+        // decode once (main.rs:486-490), then the file-parallel extraction loop (main.rs:500-508)
+        std::vector<std::string> path_list;
+        for (const Entry& e : train_files) path_list.push_back(e.path);
+        auto audio = batch_resample(path_list);
+        std::vector<std::vector<int16_t>> clips;
+        for (auto& a : audio) clips.push_back(std::move(a.second));
+        std::vector<Features> feats = extractor.extract_batch(clips);
+        std::map<std::string, Features> feature_map;
+        for (size_t i = 0; i < audio.size(); ++i) feature_map[audio[i].first] = std::move(feats[i]);
+        for (const Entry& e : train_files)
+            if (!feature_map.count(e.path)) std::fprintf(stderr, "No features found for training path: %s\n", e.path.c_str());
+
+        const size_t dataset_size = train_files.size();  // main.rs:517-519
+        size_t burn_default = (size_t)std::ceil((float)dataset_size * DEFAULT_BURN_IN_FRAC);
+        burn_default = std::min<size_t>(std::max<size_t>(burn_default, 10), 50);
+        const size_t burn_in_limit_val = have_burn ? burn_in_limit : burn_default;
+
+        size_t num_speakers = count_speakers(train_files);  // main.rs:627-650
+        const bool model_exists = exists(MODEL_PATH);
+        SimpleNeuralNet net = [&]() -> SimpleNeuralNet {
+            if (model_exists) {
+                try {
+                    SimpleNeuralNet n = SimpleNeuralNet::load(MODEL_PATH);
+                    std::printf("Loaded saved model from %s\n", MODEL_PATH);
+                    n.set_embeddings(compute_speaker_embeddings(n, extractor));
+                    return n;
+                } catch (const Error& e) {
+                    std::fprintf(stderr, "Failed to load model: %s\n", e.what());
+                    return SimpleNeuralNet(FEATURE_SIZE, 512, 256, std::max<size_t>(num_speakers, 1), seed);
+                }
+            }
+            if (num_speakers == 0) {
+                num_speakers = 1;
+                train_files[0].labelled = true;
+                train_files[0].cls = 0;
+                std::printf("No labeled speakers found \xe2\x80\x94 assigned speaker 0 to first file.\n");
+            }
+            return SimpleNeuralNet(FEATURE_SIZE, 512, 256, std::max<size_t>(num_speakers, 1), seed);
+        }();
+
+        if (!model_exists) {  // main.rs:652-669
+            std::vector<std::pair<std::string, size_t>> refs;
+            for (const Entry& e : train_files)
+                if (e.labelled) refs.emplace_back(e.path, e.cls);
+            if (!refs.empty()) {
+                const float loss = train_from_feature_map(net, feature_map, refs, TRAIN_EPOCHS, 0.01f, DROPOUT_PROB, BATCH_SIZE, seed);
+                std::printf("Initial training loss: %.4f\n", loss);
+            }
+        }
+
+        // second pass, main.rs:710-835
+        std::map<size_t, std::vector<std::vector<float>>> speaker_features;
+        std::map<size_t, std::vector<float>> speaker_embeddings;
+        {
+            const auto embeds = compute_speaker_embeddings(net, extractor);
+            for (size_t i = 0; i < embeds.size(); ++i) speaker_embeddings[i] = embeds[i].first;
+        }
+        float total_loss = 0.0f;
+        size_t loss_count = 0;
+        for (Entry& e : train_files) {
+            auto it = feature_map.find(e.path);
+            if (it == feature_map.end()) { std::fprintf(stderr, "Missing audio for %s\n", e.path.c_str()); continue; }
+            const Features& windows = it->second;
+            if (windows.len() < 5) { std::fprintf(stderr, "Skipping %s, too short\n", e.path.c_str()); continue; }
+            std::vector<float> emb = extract_embedding_from_features(net, windows);
+            normalize(emb);
+            const size_t count = loss_count;
+            const bool burn_phase = count < burn_in_limit_val;
+            const float threshold = burn_phase ? 0.5f : DEFAULT_CONF_THRESHOLD;
+            size_t speaker_id;
+            if (burn_phase && !e.labelled) {
+                speaker_id = net.output_size();
+                net.add_output_class(seed + 7919 * (loss_count + 1));
+                net.record_training_file(speaker_id, e.path);
+                e.labelled = true;
+                e.cls = speaker_id;
+            } else if (e.labelled) {
+                speaker_id = e.cls;
+            } else {
+                size_t matched = identify_speaker_from_embedding(emb, speaker_embeddings, threshold);
+                if (matched >= net.output_size()) {
+                    net.add_output_class(seed + 7919 * (loss_count + 1));
+                    matched = net.output_size() - 1;
+                }
+                e.labelled = true;
+                e.cls = matched;
+                speaker_id = matched;
+            }
+            const float lr = count < 1000 ? 0.05f : 0.01f;
+            const float loss = pretrain_from_features(net, windows, speaker_id, net.output_size(), 5, lr, DROPOUT_PROB,
+                                                      BATCH_SIZE, seed + 104729 * (loss_count + 1));
+            net.record_training_file(speaker_id, e.path);
+            total_loss += loss;
+            speaker_features[speaker_id].push_back(emb);
+            speaker_embeddings[speaker_id] = average_vectors(speaker_features[speaker_id]);
+            loss_count += 1;
+        }
+
+        // main.rs:845-891
+        const auto new_embeddings = compute_speaker_embeddings(net, extractor);
+        for (size_t i = 0; i < new_embeddings.size(); ++i) {
+            float norm = 0.0f;
+            for (float x : new_embeddings[i].first) norm += x * x;
+            std::printf("Saving Speaker %zu \xe2\x86\x92 mean_sim: %.4f, std_sim: %.4f, norm: %.4f\n", i,
+                        new_embeddings[i].second.first, new_embeddings[i].second.second, std::sqrt(norm));
+        }
+        net.set_embeddings(new_embeddings);
+        try { net.save(MODEL_PATH); } catch (const Error& e) { std::fprintf(stderr, "Failed to save model: %s\n", e.what()); }
+        std::printf("Computed %zu embeddings for %zu speakers\n", net.embeddings().size(), net.output_size());
+        if (loss_count > 0) std::printf("Average training loss: %.4f\n", total_loss / (float)loss_count);
+
+        std::vector<Entry> updated = original;  // original paths + final labels
+        for (size_t i = 0; i < updated.size(); ++i) { updated[i].labelled = train_files[i].labelled; updated[i].cls = train_files[i].cls; }
+        write_list(TRAIN_FILE_LIST, updated, false);
+        write_list(TARGET_FILE_LIST, train_files, true);
+        std::printf("Updated training file labels:\n");
+        for (const Entry& e : updated) {
+            if (e.labelled) std::printf("%s -> speaker %zu\n", e.path.c_str(), e.cls + 1);
+            else std::printf("%s -> speaker unknown\n", e.path.c_str());
+        }
+        std::printf("Processed %zu speakers in this batch.\n", count_speakers(train_files));
+        std::printf("Number of speakers discovered: %zu\n", net.output_size());
+        for (size_t i = 0; i < net.output_size(); ++i)
+            std::printf("Speaker %zu: %zu samples\n", i, speaker_features.count(i) ? speaker_features[i].size() : (size_t)0);
+        return 0;
+    } catch (const Error& e) {
+        std::fprintf(stderr, "StreamZ: %s\n", e.what());
+        return 1;
+    }
+}

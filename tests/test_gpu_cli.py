@@ -1,0 +1,188 @@
+"""model.npz / feature_cache / train_files.txt drop-in behaviour on the GPU, including the
+plumbing configuration of the task: 10 synthetic 5 s 16-bit WAV clips, 2 speakers, through
+train_files.txt and the StreamZ host binary."""
+import os
+import subprocess
+import wave
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "streamz_amd", "StreamZ")
+SR = 44100
+
+
+@pytest.fixture(scope="module")
+def sz():
+    import streamz_amd
+    return streamz_amd
+
+
+def synth(speaker, seed, seconds=5.0):
+    rng = np.random.default_rng(1234 + seed)
+    t = np.arange(int(seconds * SR)) / SR
+    f0 = 90.0 + 60.0 * speaker
+    x = sum(a * np.sin(2 * np.pi * f0 * (h + 1) * t + 0.5 * h) for h, a in enumerate([1.0, 0.6, 0.4, 0.25]))
+    x = 0.25 * x / 2.25 + 0.25 * 10 ** (-30 / 20) * rng.standard_normal(t.size)
+    return np.clip(np.round(x * 32767), -32768, 32767).astype(np.int16)
+
+
+def write_wav(path, pcm):
+    with wave.open(path, "wb") as w:
+        w.setnchannels(1)
+        w.setsampwidth(2)
+        w.setframerate(SR)
+        w.writeframes(pcm.tobytes())
+
+
+def test_model_npz_round_trip_and_numpy_interop(sz, tmp_path):
+    rng = np.random.default_rng(0)
+    net = sz.SimpleNeuralNet(60, 32, 16, 3, seed=5)
+    net.record_training_file(0, "a/x.wav")
+    net.record_training_file(0, "a/y.wav")
+    net.record_training_file(0, "a/x.wav")  # duplicates are not recorded twice (lib.rs:859-861)
+    net.record_training_file(2, "c.wav")
+    net.set_dataset_specs(44100, 16)
+    emb = [(rng.standard_normal(16).astype(np.float32), 0.9, 0.01) for _ in range(3)]
+    net.set_embeddings(emb)
+    p = str(tmp_path / "model.npz")
+    net.save(p)
+    z = np.load(p)
+    params = net.get_params()
+    # member set and shapes of lib.rs:1083-1127
+    np.testing.assert_array_equal(z["w1"], params[0])
+    np.testing.assert_array_equal(z["b1"], params[1])
+    np.testing.assert_array_equal(z["w2"], params[2])
+    np.testing.assert_array_equal(z["b2"], params[3])
+    assert z["sample_rate"].tolist() == [44100] and z["bits"].tolist() == [16] and z["num_speakers"].tolist() == [3]
+    for c in range(3):
+        np.testing.assert_array_equal(z[f"w3_{c + 1}"], params[4][:, c])   # 1-based, one column per class
+        np.testing.assert_array_equal(z[f"b3_{c + 1}"], params[5][c:c + 1])
+    assert bytes(z["speaker_0_files"]).decode() == "a/x.wav\na/y.wav"        # 0-based
+    assert z["speaker_1_files"].size == 0 and bytes(z["speaker_2_files"]).decode() == "c.wav"
+    assert z["speaker_embeddings"].shape == (3, 16) and z["speaker_mean_sims"].shape == (3,)
+    back = sz.SimpleNeuralNet.load(p)
+    assert back.dims() == (60, 32, 16, 3)
+    for a, b in zip(back.get_params(), params):
+        np.testing.assert_array_equal(a, b)
+    assert back.file_lists() == [["a/x.wav", "a/y.wav"], [], ["c.wav"]]
+    for (v, m, s), (v0, m0, s0) in zip(back.embeddings(), emb):
+        np.testing.assert_array_equal(v, v0)
+        assert abs(m - m0) < 1e-7 and abs(s - s0) < 1e-7
+    x = rng.standard_normal((5, 60)).astype(np.float32)
+    np.testing.assert_array_equal(back.forward(x), net.forward(x))
+
+
+def test_load_accepts_numpy_written_and_legacy_monolithic_layouts(sz, tmp_path):
+    rng = np.random.default_rng(1)
+    w1, b1 = rng.standard_normal((60, 8)).astype(np.float32), rng.standard_normal(8).astype(np.float32)
+    w2, b2 = rng.standard_normal((8, 4)).astype(np.float32), rng.standard_normal(4).astype(np.float32)
+    w3, b3 = rng.standard_normal((4, 2)).astype(np.float32), rng.standard_normal(2).astype(np.float32)
+    common = dict(w1=w1, b1=b1, w2=w2, b2=b2, sample_rate=np.array([44100], np.int64), bits=np.array([16], np.int64))
+    p = str(tmp_path / "percol.npz")
+    np.savez_compressed(p, **common, num_speakers=np.array([2], np.int64), w3_1=w3[:, 0], b3_1=b3[:1], w3_2=w3[:, 1],
+                        b3_2=b3[1:])
+    n = sz.SimpleNeuralNet.load(p)
+    np.testing.assert_array_equal(n.get_params()[4], w3)
+    np.testing.assert_array_equal(n.get_params()[5], b3)
+    p2 = str(tmp_path / "legacy.npz")
+    np.savez(p2, **common, w3=w3, b3=b3)  # lib.rs:1199-1207
+    n2 = sz.SimpleNeuralNet.load(p2)
+    assert n2.output_size() == 2
+    np.testing.assert_array_equal(n2.get_params()[4], w3)
+    with pytest.raises(sz.StreamzError):
+        sz.SimpleNeuralNet.load(str(tmp_path / "nope.npz"))
+    p3 = str(tmp_path / "broken.npz")
+    np.savez(p3, w1=w1)
+    with pytest.raises(sz.StreamzError):
+        sz.SimpleNeuralNet.load(p3)
+
+
+def test_load_cached_features_miss_then_hit(sz, tmp_path, monkeypatch):
+    monkeypatch.chdir(tmp_path)
+    os.makedirs("data")
+    pcm = synth(0, 3, seconds=1.0)
+    write_wav("data/clip.wav", pcm)
+    ext = sz.FeatureExtractor()
+    direct = ext.extract(pcm)
+    first = sz.load_cached_features("data/clip.wav", ext)
+    np.testing.assert_array_equal(first, direct)
+    cache = os.path.join("feature_cache", "data_clip.wav.npy")  # '/' -> '_' (lib.rs:553)
+    assert os.path.exists(cache)
+    on_disk = np.load(cache)
+    assert on_disk.dtype == np.float32 and on_disk.shape == direct.shape
+    np.testing.assert_array_equal(on_disk, direct)
+    # a hit returns the cached array without touching the audio
+    np.save(cache, (direct + 1.0).astype(np.float32))
+    np.testing.assert_array_equal(sz.load_cached_features("data/clip.wav", ext), direct + 1.0)
+    # too short for one window: empty result, nothing cached (lib.rs:573)
+    write_wav("data/short.wav", pcm[:500])
+    assert sz.load_cached_features("data/short.wav", ext).shape == (0, 60)
+    assert not os.path.exists(os.path.join("feature_cache", "data_short.wav.npy"))
+    with pytest.raises(sz.StreamzError):
+        sz.load_cached_features("data/absent.wav", ext)
+
+
+def test_cli_trains_ten_clips_two_speakers(sz, tmp_path):
+    assert os.path.exists(CLI), "StreamZ host binary not built"
+    os.makedirs(tmp_path / "wav")
+    lines, labels, clips = [], [], []
+    for i in range(10):
+        spk = i % 2
+        pcm = synth(spk, i)
+        write_wav(str(tmp_path / "wav" / f"clip{i}.wav"), pcm)
+        lines.append(f"wav/clip{i}.wav, {spk}" if i != 7 else f"  wav/clip{i}.wav ,{spk}  ")  # trimmed (main.rs:47-52)
+        labels.append(spk)
+        clips.append(pcm)
+    (tmp_path / "train_files.txt").write_text("\n".join(lines) + "\n\n")
+    r = subprocess.run([CLI, "--seed", "11"], cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    assert "Initial training loss:" in r.stdout and "Average training loss:" in r.stdout
+    # lists are rewritten: original paths + labels (main.rs:870-876)
+    assert (tmp_path / "train_files.txt").read_text().splitlines() == [f"wav/clip{i}.wav,{i % 2}" for i in range(10)]
+    assert (tmp_path / "target_files.txt").read_text().splitlines() == [f"wav/clip{i}.wav,{i % 2}" for i in range(10)]
+    # model.npz: numpy-readable, CLI network sizes (main.rs:649), both speakers' file lists
+    z = np.load(tmp_path / "model.npz")
+    assert z["w1"].shape == (60, 512) and z["w2"].shape == (512, 256) and z["num_speakers"].tolist() == [2]
+    assert bytes(z["speaker_0_files"]).decode().split("\n") == [f"wav/clip{i}.wav" for i in range(0, 10, 2)]
+    assert z["speaker_embeddings"].shape == (2, 256)
+    # feature cache written for every training file by compute_speaker_embeddings (main.rs:845)
+    ext = sz.FeatureExtractor()
+    for i in (0, 9):
+        cached = np.load(tmp_path / "feature_cache" / f"wav_clip{i}.wav.npy")
+        assert cached.shape == (550, 60)
+        np.testing.assert_array_equal(cached, ext.extract(clips[i]))
+    # The reference trains file after file (100 epochs each, then 5 more in the second pass), so
+    # the model ends up favouring the speaker of the last file; step-level parity of that loop
+    # is checked with injected random streams in test_gpu_parity.py.  Here: the numbers are
+    # finite and the most recently trained clip is recognised.
+    import re
+    init_loss = float(re.search(r"Initial training loss: ([0-9.eE+-]+)", r.stdout).group(1))
+    avg_loss = float(re.search(r"Average training loss: ([0-9.eE+-]+)", r.stdout).group(1))
+    assert 0.0 <= init_loss < 5.0 and 0.0 <= avg_loss < 5.0
+    net = sz.SimpleNeuralNet.load(str(tmp_path / "model.npz"))
+    assert np.isfinite(net.get_flat()).all()
+    ids = sz.identify_speaker_list(net, clips[9], 0.5, ext)
+    assert ids and ids[0] == labels[9]
+    # second run: the model is loaded and the 100-epoch pass is skipped (main.rs:652)
+    r2 = subprocess.run([CLI, "--seed", "11"], cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert r2.returncode == 0, r2.stderr
+    assert "Loaded saved model from model.npz" in r2.stdout and "Initial training loss:" not in r2.stdout
+
+
+def test_cli_unlabelled_list_discovers_speakers(sz, tmp_path):
+    os.makedirs(tmp_path / "wav")
+    for i in range(4):
+        write_wav(str(tmp_path / "wav" / f"u{i}.wav"), synth(i % 2, 40 + i, seconds=2.0))
+    (tmp_path / "train_files.txt").write_text("".join(f"wav/u{i}.wav\n" for i in range(4)))
+    r = subprocess.run([CLI, "--seed", "3", "--burn-in-limit", "2"], cwd=tmp_path, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr
+    assert "No labeled speakers found" in r.stdout
+    rows = (tmp_path / "train_files.txt").read_text().splitlines()
+    assert len(rows) == 4 and all("," in row for row in rows)  # every file ends up labelled
+    z = np.load(tmp_path / "model.npz")
+    assert int(z["num_speakers"][0]) >= 2
