@@ -1,0 +1,262 @@
+// LDS-tiled f32 GEMM on v_mfma_f32_32x32x2_f32 with fused epilogues; included by net.hip and by
+// the tuning harness tools/gemm_bench.hip.
+//
+// C[M][N] = epilogue(sum_k A(m,k) B(k,n)).  Block tile TM x 128 (TM = 128: 4 waves as 2x2 of
+// 64x64; TM = 64: 1x4 of 64x32), K tile KT.  Operand tiles are kept k-major in LDS (row stride
+// 132 floats) so that an MFMA fragment read is 32 consecutive floats per half-wave.  The next K
+// tile is fetched into registers while the current one is multiplied; with DB the LDS tiles are
+// double-buffered and one barrier per K tile suffices.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sz {
+namespace gemm {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128, BN = 128;
+constexpr int LDT = BM + 4;  // LDS row stride (floats) of k-major operands: 16-byte aligned rows
+constexpr int LDR = BM + 1;  // LDS row stride of operands transposed on the way in: scalar stores <= 2-way
+constexpr int kGemmThreads = 256;
+
+enum AMode { A_ROWS = 0 /* A[m][k] */, A_KROWS = 1 /* A[k][m] */ };
+enum BMode { B_KROWS = 0 /* B[k][n] */, B_ROWS = 1 /* B[n][k] */ };
+enum Epi {
+    EPI_BIAS_RELU = 0,  // C = relu(acc + bias[n])        (v > 0 ? v : 0, lib.rs:882)
+    EPI_BIAS_TANH = 1,  // C = tanh(acc + bias[n])        (lib.rs:883)
+    EPI_BIAS = 2,       // C = acc + bias[n]
+    EPI_MUL_DTANH = 3,  // C = acc * (1 - aux^2)          (lib.rs:1034)
+    EPI_MUL_DRELU = 4,  // C = acc * (aux > 0)            (lib.rs:1039-1040)
+    EPI_SLAB = 5        // C[z] = acc                     (split-K partial)
+};
+
+struct GemmArgs {
+    const float* A;
+    const float* B;
+    float* C;
+    int M, N, K;
+    int lda, ldb, ldc;
+    const float* bias;
+    const float* aux;
+    int ldaux;
+    int k_chunk;   // K range handled by one blockIdx.z
+    int a_vec, b_vec;
+    int ones_row = -1;  // A_KROWS only: logical row M-1 of A is all ones (bias-gradient row)
+};
+
+struct Frag4 { float v[4]; };
+
+__device__ __forceinline__ Frag4 load4(const float* base, int64_t row, int col, int ld, int row_max, int col_max,
+                                       int vec)
+{
+    Frag4 r;
+    if (row < row_max && vec && col + 3 < col_max) {
+        const float4 q = *reinterpret_cast<const float4*>(base + row * ld + col);
+        r.v[0] = q.x; r.v[1] = q.y; r.v[2] = q.z; r.v[3] = q.w;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            r.v[j] = (row < row_max && col + j < col_max) ? base[row * ld + col + j] : 0.0f;
+    }
+    return r;
+}
+
+// Tile whose global rows run along the tile dimension and whose columns run along k
+// (A[m][k], B[n][k]): TR rows x 16 k, stored transposed (k-major) into LDS.
+template <int TR, int KT>
+__device__ __forceinline__ void fetch_rows(const float* base, int ld, int r0, int r_max, int k0, int k_max, int vec,
+                                           Frag4 (&f)[TR * KT / 1024])
+{
+#pragma unroll
+    for (int i = 0; i < TR * KT / 1024; ++i) {
+        const int idx = threadIdx.x + kGemmThreads * i;
+        f[i] = load4(base, r0 + idx / (KT / 4), k0 + 4 * (idx % (KT / 4)), ld, r_max, k_max, vec);
+    }
+}
+template <int TR, int KT>
+__device__ __forceinline__ void stash_rows(float* S, const Frag4 (&f)[TR * KT / 1024])
+{
+#pragma unroll
+    for (int i = 0; i < TR * KT / 1024; ++i) {
+        const int idx = threadIdx.x + kGemmThreads * i;
+        const int row = idx / (KT / 4), kq = idx % (KT / 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) S[(4 * kq + j) * LDR + row] = f[i].v[j];
+    }
+}
+// Tile whose global rows run along k (A[k][m], B[k][n]): 16 k x TR, copied straight.
+template <int TR, int KT>
+__device__ __forceinline__ void fetch_krows(const float* base, int ld, int c0, int c_max, int k0, int k_max, int vec,
+                                            int ones_col, Frag4 (&f)[TR * KT / 1024])
+{
+#pragma unroll
+    for (int i = 0; i < TR * KT / 1024; ++i) {
+        const int idx = threadIdx.x + kGemmThreads * i;
+        const int krow = k0 + idx / (TR / 4), col = c0 + 4 * (idx % (TR / 4));
+        f[i] = load4(base, krow, col, ld, k_max, c_max, vec);
+        if (ones_col >= 0 && krow < k_max) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (col + j == ones_col) f[i].v[j] = 1.0f;
+        }
+    }
+}
+template <int TR, int KT>
+__device__ __forceinline__ void stash_krows(float* S, const Frag4 (&f)[TR * KT / 1024])
+{
+#pragma unroll
+    for (int i = 0; i < TR * KT / 1024; ++i) {
+        const int idx = threadIdx.x + kGemmThreads * i;
+        float4 q;
+        q.x = f[i].v[0]; q.y = f[i].v[1]; q.z = f[i].v[2]; q.w = f[i].v[3];
+        *reinterpret_cast<float4*>(S + (idx / (TR / 4)) * LDT + 4 * (idx % (TR / 4))) = q;
+    }
+}
+
+// Unguarded variants for tiles that lie completely inside the operands with 16-byte aligned rows.
+template <int TR, int KT>
+__device__ __forceinline__ void fetch_rows_fast(const float* base, int ld, int r0, int k0, Frag4 (&f)[TR * KT / 1024])
+{
+#pragma unroll
+    for (int i = 0; i < TR * KT / 1024; ++i) {
+        const int idx = threadIdx.x + kGemmThreads * i;
+        const float4 q = *reinterpret_cast<const float4*>(base + (int64_t)(r0 + idx / (KT / 4)) * ld + k0 + 4 * (idx % (KT / 4)));
+        f[i].v[0] = q.x; f[i].v[1] = q.y; f[i].v[2] = q.z; f[i].v[3] = q.w;
+    }
+}
+template <int TR, int KT>
+__device__ __forceinline__ void fetch_krows_fast(const float* base, int ld, int c0, int k0, Frag4 (&f)[TR * KT / 1024])
+{
+#pragma unroll
+    for (int i = 0; i < TR * KT / 1024; ++i) {
+        const int idx = threadIdx.x + kGemmThreads * i;
+        const float4 q = *reinterpret_cast<const float4*>(base + (int64_t)(k0 + idx / (TR / 4)) * ld + c0 + 4 * (idx % (TR / 4)));
+        f[i].v[0] = q.x; f[i].v[1] = q.y; f[i].v[2] = q.z; f[i].v[3] = q.w;
+    }
+}
+
+// TAG only separates instantiations, so that each call site is its own kernel in a profile.
+// TM = rows of the block tile, KT = K tile (16 or 32), DB = double-buffered LDS tiles.
+template <int AM, int BMd, int EPI, int TAG, int TM, int KT, int DB>
+__global__ __launch_bounds__(kGemmThreads) void gemm_kernel(GemmArgs g)
+{
+    constexpr int BK = KT;
+    constexpr int WAVES_M = TM / 64, WAVES_N = 4 / WAVES_M;
+    constexpr int WN = BN / WAVES_N;  // columns per wave: 64 or 32
+    constexpr int TN = WN / 32;       // 32-wide MFMA tiles per wave along N
+    constexpr int LDA = AM == A_ROWS ? LDR : LDT;
+    constexpr int LDB = BMd == B_ROWS ? LDR : LDT;
+    __shared__ __attribute__((aligned(16))) float As_[(DB ? 2 : 1) * BK * LDT];
+    __shared__ __attribute__((aligned(16))) float Bs_[(DB ? 2 : 1) * BK * LDT];
+    const int m0 = blockIdx.y * TM, n0 = blockIdx.x * BN;
+    const int k_begin = blockIdx.z * g.k_chunk;
+    const int k_end = min(g.K, k_begin + g.k_chunk);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int a_cols = g.ones_row >= 0 ? g.M - 1 : g.M;  // columns of A that exist in memory (A_KROWS)
+
+    f32x16 acc[2][TN];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    Frag4 fa[TM * BK / 1024], fb[BN * BK / 1024];
+    // interior tiles (the common case) take straight-line 16-byte loads; edge tiles are guarded
+    const bool a_inside = g.a_vec && g.ones_row < 0 && m0 + TM <= g.M;
+    const bool b_inside = g.b_vec && n0 + BN <= g.N;
+    auto fetch = [&](int k0) {
+        const bool k_inside = k0 + BK <= k_end;
+        if (a_inside && k_inside) {
+            if (AM == A_ROWS) fetch_rows_fast<TM, BK>(g.A, g.lda, m0, k0, fa);
+            else fetch_krows_fast<TM, BK>(g.A, g.lda, m0, k0, fa);
+        } else {
+            if (AM == A_ROWS) fetch_rows<TM, BK>(g.A, g.lda, m0, g.M, k0, k_end, g.a_vec, fa);
+            else fetch_krows<TM, BK>(g.A, g.lda, m0, a_cols, k0, k_end, g.a_vec, g.ones_row, fa);
+        }
+        if (b_inside && k_inside) {
+            if (BMd == B_ROWS) fetch_rows_fast<BN, BK>(g.B, g.ldb, n0, k0, fb);
+            else fetch_krows_fast<BN, BK>(g.B, g.ldb, n0, k0, fb);
+        } else {
+            if (BMd == B_ROWS) fetch_rows<BN, BK>(g.B, g.ldb, n0, g.N, k0, k_end, g.b_vec, fb);
+            else fetch_krows<BN, BK>(g.B, g.ldb, n0, g.N, k0, k_end, g.b_vec, -1, fb);
+        }
+    };
+    auto stash = [&](int buf) {
+        float* As = As_ + buf * BK * LDT;
+        float* Bs = Bs_ + buf * BK * LDT;
+        if (AM == A_ROWS) stash_rows<TM, BK>(As, fa); else stash_krows<TM, BK>(As, fa);
+        if (BMd == B_ROWS) stash_rows<BN, BK>(Bs, fb); else stash_krows<BN, BK>(Bs, fb);
+    };
+    if (k_begin < k_end) fetch(k_begin);
+    if (DB && k_begin < k_end) { stash(0); __syncthreads(); }
+    int buf = 0;
+    for (int k0 = k_begin; k0 < k_end; k0 += BK) {
+        if (!DB) {
+            __syncthreads();
+            stash(0);
+            __syncthreads();
+        }
+        if (k0 + BK < k_end) fetch(k0 + BK);
+        const float* As = As_ + buf * BK * LDT;
+        const float* Bs = Bs_ + buf * BK * LDT;
+        // fragments of k-step kk+2 are read from LDS while the MFMAs of k-step kk run
+        const float* ar = As + half * LDA + wm * 64 + l31;
+        const float* br = Bs + half * LDB + wn * WN + l31;
+        float fa0[2], fa1[2], fbn[2][TN];
+        fa0[0] = ar[0]; fa1[0] = ar[32];
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) fbn[0][tn] = br[32 * tn];
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            const int cur = (kk >> 1) & 1, nxt = cur ^ 1;
+            if (kk + 2 < BK) {
+                fa0[nxt] = ar[(kk + 2) * LDA]; fa1[nxt] = ar[(kk + 2) * LDA + 32];
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) fbn[nxt][tn] = br[(kk + 2) * LDB + 32 * tn];
+            }
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                acc[0][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[cur], fbn[cur][tn], acc[0][tn], 0, 0, 0);
+                acc[1][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[cur], fbn[cur][tn], acc[1][tn], 0, 0, 0);
+            }
+        }
+        if (DB) {
+            if (k0 + BK < k_end) stash(buf ^ 1);
+            __syncthreads();
+            buf ^= 1;
+        }
+    }
+
+    float* C = g.C;
+    if (EPI == EPI_SLAB) C += (size_t)blockIdx.z * (size_t)g.M * (size_t)g.ldc;
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            const int col = n0 + wn * WN + tn * 32 + l31;
+            if (col >= g.N) continue;
+            float bias = 0.0f;
+            if (EPI == EPI_BIAS_RELU || EPI == EPI_BIAS_TANH || EPI == EPI_BIAS) bias = g.bias[col];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (row >= g.M) continue;
+                float v = acc[tm][tn][r];
+                if (EPI == EPI_BIAS_RELU) { v += bias; v = v > 0.0f ? v : 0.0f; }
+                else if (EPI == EPI_BIAS_TANH) v = tanhf(v + bias);
+                else if (EPI == EPI_BIAS) v += bias;
+                else if (EPI == EPI_MUL_DTANH) { const float h = g.aux[(size_t)row * g.ldaux + col]; v *= (1.0f - h * h); }
+                else if (EPI == EPI_MUL_DRELU) { const float h = g.aux[(size_t)row * g.ldaux + col]; v *= (h > 0.0f ? 1.0f : 0.0f); }
+                C[(size_t)row * g.ldc + col] = v;
+            }
+        }
+}
+
+
+}  // namespace gemm
+}  // namespace sz

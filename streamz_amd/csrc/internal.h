@@ -57,7 +57,8 @@ int plan_run(Plan* p, const int16_t* pcm_dev, float* feats_dev, hipStream_t stre
 struct Workspace {
     uint64_t rows = 0;  // capacity in rows
     uint32_t out = 0;   // output width it was sized for
-    float *xd = nullptr, *h1 = nullptr, *h2 = nullptr, *p = nullptr, *d2 = nullptr, *d1 = nullptr, *slab = nullptr;
+    float *xd = nullptr, *h1 = nullptr, *h2 = nullptr, *p = nullptr, *d2 = nullptr, *d1 = nullptr, *slab = nullptr,
+          *w2t = nullptr;
     uint8_t* live = nullptr;
     uint64_t slab_floats = 0;
 };

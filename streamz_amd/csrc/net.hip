@@ -10,6 +10,7 @@
 #include <mutex>
 #include <new>
 
+#include "gemm_kernel.h"
 #include "internal.h"
 #include "prof.h"
 #include "streamz_hip.h"
@@ -18,169 +19,12 @@ namespace sz {
 
 namespace {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-constexpr int BM = 128, BN = 128, BK = 16;
-constexpr int LDT = BM + 4;  // LDS row stride in floats: keeps transposing stores <= 2-way
-constexpr int kGemmThreads = 256;
-
-enum AMode { A_ROWS = 0 /* A[m][k] */, A_KROWS = 1 /* A[k][m] */ };
-enum BMode { B_KROWS = 0 /* B[k][n] */, B_ROWS = 1 /* B[n][k] */ };
-enum Epi {
-    EPI_BIAS_RELU = 0,  // C = relu(acc + bias[n])        (v > 0 ? v : 0, lib.rs:882)
-    EPI_BIAS_TANH = 1,  // C = tanh(acc + bias[n])        (lib.rs:883)
-    EPI_BIAS = 2,       // C = acc + bias[n]
-    EPI_MUL_DTANH = 3,  // C = acc * (1 - aux^2)          (lib.rs:1034)
-    EPI_MUL_DRELU = 4,  // C = acc * (aux > 0)            (lib.rs:1039-1040)
-    EPI_SLAB = 5        // C[z] = acc                     (split-K partial)
-};
-
-struct GemmArgs {
-    const float* A;
-    const float* B;
-    float* C;
-    int M, N, K;
-    int lda, ldb, ldc;
-    const float* bias;
-    const float* aux;
-    int ldaux;
-    int k_chunk;  // K range handled by one blockIdx.z
-    int a_vec, b_vec;
-};
-
-struct Frag4 { float v[4]; };
-
-__device__ __forceinline__ Frag4 load4(const float* base, int64_t row, int col, int ld, int row_max, int col_max,
-                                       int vec)
-{
-    Frag4 r;
-    if (row < row_max && vec && col + 3 < col_max) {
-        const float4 q = *reinterpret_cast<const float4*>(base + row * ld + col);
-        r.v[0] = q.x; r.v[1] = q.y; r.v[2] = q.z; r.v[3] = q.w;
-    } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            r.v[j] = (row < row_max && col + j < col_max) ? base[row * ld + col + j] : 0.0f;
-    }
-    return r;
-}
-
-// Tile whose global rows run along the tile dimension and whose columns run along k
-// (A[m][k], B[n][k]): 128 rows x 16 k, stored transposed (k-major) into LDS.
-__device__ __forceinline__ void fetch_rows(const float* base, int ld, int r0, int r_max, int k0, int k_max, int vec,
-                                           Frag4 (&f)[2])
-{
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int idx = threadIdx.x + kGemmThreads * i;
-        f[i] = load4(base, r0 + (idx >> 2), k0 + 4 * (idx & 3), ld, r_max, k_max, vec);
-    }
-}
-__device__ __forceinline__ void stash_rows(float* S, const Frag4 (&f)[2])
-{
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int idx = threadIdx.x + kGemmThreads * i;
-        const int row = idx >> 2, kq = idx & 3;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) S[(4 * kq + j) * LDT + row] = f[i].v[j];
-    }
-}
-// Tile whose global rows run along k (A[k][m], B[k][n]): 16 k x 128, copied straight.
-__device__ __forceinline__ void fetch_krows(const float* base, int ld, int c0, int c_max, int k0, int k_max, int vec,
-                                            Frag4 (&f)[2])
-{
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int idx = threadIdx.x + kGemmThreads * i;
-        f[i] = load4(base, k0 + (idx >> 5), c0 + 4 * (idx & 31), ld, k_max, c_max, vec);
-    }
-}
-__device__ __forceinline__ void stash_krows(float* S, const Frag4 (&f)[2])
-{
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int idx = threadIdx.x + kGemmThreads * i;
-        float4 q;
-        q.x = f[i].v[0]; q.y = f[i].v[1]; q.z = f[i].v[2]; q.w = f[i].v[3];
-        *reinterpret_cast<float4*>(S + (idx >> 5) * LDT + 4 * (idx & 31)) = q;
-    }
-}
-
-// TAG only separates instantiations, so that each call site is its own kernel in a profile.
-template <int AM, int BMd, int EPI, int TAG>
-__global__ __launch_bounds__(kGemmThreads) void gemm_kernel(GemmArgs g)
-{
-    __shared__ __attribute__((aligned(16))) float As[BK * LDT];
-    __shared__ __attribute__((aligned(16))) float Bs[BK * LDT];
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    const int k_begin = blockIdx.z * g.k_chunk;
-    const int k_end = min(g.K, k_begin + g.k_chunk);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int l31 = lane & 31, half = lane >> 5;
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
-    Frag4 fa[2], fb[2];
-    auto fetch = [&](int k0) {
-        if (AM == A_ROWS) fetch_rows(g.A, g.lda, m0, g.M, k0, k_end, g.a_vec, fa);
-        else fetch_krows(g.A, g.lda, m0, g.M, k0, k_end, g.a_vec, fa);
-        if (BMd == B_ROWS) fetch_rows(g.B, g.ldb, n0, g.N, k0, k_end, g.b_vec, fb);
-        else fetch_krows(g.B, g.ldb, n0, g.N, k0, k_end, g.b_vec, fb);
-    };
-    if (k_begin < k_end) fetch(k_begin);
-    for (int k0 = k_begin; k0 < k_end; k0 += BK) {
-        __syncthreads();
-        if (AM == A_ROWS) stash_rows(As, fa); else stash_krows(As, fa);
-        if (BMd == B_ROWS) stash_rows(Bs, fb); else stash_krows(Bs, fb);
-        __syncthreads();
-        if (k0 + BK < k_end) fetch(k0 + BK);
-#pragma unroll
-        for (int kk = 0; kk < BK; kk += 2) {
-            const float* ar = As + (kk + half) * LDT + wm * 64 + l31;
-            const float* br = Bs + (kk + half) * LDT + wn * 64 + l31;
-            const float a0 = ar[0], a1 = ar[32];
-            const float b0 = br[0], b1 = br[32];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-        }
-    }
-
-    float* C = g.C;
-    if (EPI == EPI_SLAB) C += (size_t)blockIdx.z * (size_t)g.M * (size_t)g.ldc;
-#pragma unroll
-    for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < 2; ++tn) {
-            const int col = n0 + wn * 64 + tn * 32 + l31;
-            if (col >= g.N) continue;
-            float bias = 0.0f;
-            if (EPI == EPI_BIAS_RELU || EPI == EPI_BIAS_TANH || EPI == EPI_BIAS) bias = g.bias[col];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (row >= g.M) continue;
-                float v = acc[tm][tn][r];
-                if (EPI == EPI_BIAS_RELU) { v += bias; v = v > 0.0f ? v : 0.0f; }
-                else if (EPI == EPI_BIAS_TANH) v = tanhf(v + bias);
-                else if (EPI == EPI_BIAS) v += bias;
-                else if (EPI == EPI_MUL_DTANH) { const float h = g.aux[(size_t)row * g.ldaux + col]; v *= (1.0f - h * h); }
-                else if (EPI == EPI_MUL_DRELU) { const float h = g.aux[(size_t)row * g.ldaux + col]; v *= (h > 0.0f ? 1.0f : 0.0f); }
-                C[(size_t)row * g.ldc + col] = v;
-            }
-        }
-}
+using namespace gemm;
 
 inline int vec_ok(const void* p, int ld) { return (((uintptr_t)p & 15) == 0 && (ld & 3) == 0) ? 1 : 0; }
+
+constexpr int kGemmKT = 32, kGemmDB = 0;  // K tile and LDS double-buffering of the shipped kernels
+constexpr int BK = kGemmKT;
 
 enum GemmTag { T_FWD1 = 0, T_FWD2, T_FWD3, T_DELTA2, T_DELTA1, T_DW3, T_DW2, T_DW1 };
 const char* const kGemmTagName[] = {"fwd1", "fwd2", "fwd3", "delta2", "delta1", "dw3", "dw2", "dw1"};
@@ -191,10 +35,13 @@ int launch_gemm(GemmArgs g, int splits, hipStream_t s)
     if (g.M <= 0 || g.N <= 0) return SZH_OK;
     g.a_vec = vec_ok(g.A, g.lda);
     g.b_vec = vec_ok(g.B, g.ldb);
-    dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, splits);
-    {
-        ProfScope prof(kGemmTagName[TAG], s);
-        hipLaunchKernelGGL((gemm_kernel<AM, BMd, EPI, TAG>), grid, dim3(kGemmThreads), 0, s, g);
+    ProfScope prof(kGemmTagName[TAG], s);
+    if (g.M <= 64) {
+        dim3 grid((g.N + BN - 1) / BN, (g.M + 63) / 64, splits);
+        hipLaunchKernelGGL((gemm_kernel<AM, BMd, EPI, TAG, 64, kGemmKT, kGemmDB>), grid, dim3(kGemmThreads), 0, s, g);
+    } else {
+        dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, splits);
+        hipLaunchKernelGGL((gemm_kernel<AM, BMd, EPI, TAG, 128, kGemmKT, kGemmDB>), grid, dim3(kGemmThreads), 0, s, g);
     }
     SZ_HIP(hipGetLastError());
     return SZH_OK;
@@ -311,6 +158,224 @@ __global__ void vote_kernel(const float* __restrict__ P, uint64_t rows, int C, f
         if (hist[j]) atomicAdd(&counts[j], (unsigned long long)hist[j]);
 }
 
+// ---- output head for small class counts ------------------------------------------------
+// For C <= 32 and hidden2 <= 256 the three contractions around the output layer are far too
+// thin for 128-wide matrix tiles, so one kernel does them with vector FMAs on 32-row tiles
+// held in LDS: logits = h2.w3 + b3, softmax, loss, delta3 = o - t (lib.rs:1022-1028),
+// dW3 += h2^T.delta3, db3 += sum delta3 (lib.rs:1029-1033), delta2 = (delta3.w3^T)(1 - h2^2)
+// (lib.rs:1034), db2 += sum delta2 (lib.rs:1038).  delta2 goes to global memory; the gradient
+// partials of each workgroup go to a slab that slab_reduce_kernel sums.
+constexpr int kHeadRows = 32;
+constexpr int kHeadThreads = 256;
+
+struct HeadArgs {
+    const float* h2;       // [rows][H2]
+    const float* w3;       // [H2][C]
+    const float* b3;       // [C]
+    const float* target;   // [C] shared target, or
+    const int32_t* labels; // [rows]
+    const uint8_t* live;   // [rows]
+    float* d2;             // [rows][H2] out
+    float* slab_w3;        // [blocks][H2*C + C]  (dW3 then db3, the layout of the gradient vector)
+    float* slab_b2;        // [blocks][H2]
+    double* stats;
+    uint64_t rows;
+    int H2, C, Cp;         // Cp = C rounded up to a multiple of 4
+    int tiles_per_block;
+};
+
+template <int CP>
+__global__ __launch_bounds__(kHeadThreads) void head_kernel(HeadArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float hs[];
+    const int H2 = a.H2, C = a.C;
+    constexpr int Cp = CP, Cq = CP / 4;
+    const int LDH = H2 + 4;
+    float* H2s = hs;                       // [32][H2+4]   h2 tile, later delta2 in place
+    float* W3s = H2s + kHeadRows * LDH;    // [H2][Cp]     w3, zero-padded columns
+    float* W3T = W3s + H2 * Cp;            // [Cp][H2+4]   w3 transposed
+    float* D3s = W3T + Cp * LDH;           // [32][Cp]     logits -> delta3
+    const int tid = threadIdx.x;
+
+    for (int i = tid; i < H2 * Cp; i += kHeadThreads) {
+        const int k = i / Cp, c = i - k * Cp;
+        const float v = c < C ? a.w3[(size_t)k * C + c] : 0.0f;
+        W3s[i] = v;
+        W3T[c * LDH + k] = v;
+    }
+    float acc_w3[CP];
+#pragma unroll
+    for (int c = 0; c < CP; ++c) acc_w3[c] = 0.0f;
+    float acc_b3 = 0.0f, acc_b2 = 0.0f;
+    double loss_sum = 0.0, live_sum = 0.0;
+
+    for (int t = 0; t < a.tiles_per_block; ++t) {
+        const uint64_t r0 = ((uint64_t)blockIdx.x * a.tiles_per_block + t) * kHeadRows;
+        if (r0 >= a.rows) break;
+        const int nr = (int)min((uint64_t)kHeadRows, a.rows - r0);
+        __syncthreads();  // previous tile fully consumed; W3 tables written
+        // h2 tile -> LDS (rows past the end are zero)
+        for (int i = tid; i < kHeadRows * (H2 / 4); i += kHeadThreads) {
+            const int r = i / (H2 / 4), q = i - r * (H2 / 4);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < nr) v = *reinterpret_cast<const float4*>(a.h2 + (r0 + r) * H2 + 4 * q);
+            *reinterpret_cast<float4*>(H2s + r * LDH + 4 * q) = v;
+        }
+        __syncthreads();
+        // logits: 4 classes of one row per work item
+        for (int o = tid; o < kHeadRows * Cq; o += kHeadThreads) {
+            const int r = o / Cq, cg = o - r * Cq;
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+            const float* hr = H2s + r * LDH;
+            const float* wr = W3s + 4 * cg;
+#pragma unroll 8
+            for (int k = 0; k < H2; ++k) {
+                const float h = hr[k];
+                const float4 w = *reinterpret_cast<const float4*>(wr + k * Cp);
+                s0 += h * w.x; s1 += h * w.y; s2 += h * w.z; s3 += h * w.w;
+            }
+            float* d = D3s + r * Cp + 4 * cg;
+            d[0] = s0; d[1] = s1; d[2] = s2; d[3] = s3;
+        }
+        __syncthreads();
+        // softmax, loss and delta3: 8 lanes per row, classes s, s+8, s+16, s+24 each
+        {
+            const int r = tid >> 3, sl = tid & 7;
+            float* p = D3s + r * Cp;
+            const bool row_ok = r < nr;
+            float v[4];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int j = sl + 8 * i;
+                v[i] = (row_ok && j < C) ? p[j] + a.b3[j] : -INFINITY;
+                mx = fmaxf(mx, v[i]);
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 4));
+            mx = fmaxf(mx, __shfl_xor(mx, 2));
+            mx = fmaxf(mx, __shfl_xor(mx, 1));
+            float sum = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int j = sl + 8 * i;
+                v[i] = (row_ok && j < C) ? expf(v[i] - mx) : 0.0f;
+                sum += v[i];
+            }
+            sum += __shfl_xor(sum, 4);
+            sum += __shfl_xor(sum, 2);
+            sum += __shfl_xor(sum, 1);
+            const bool alive = row_ok && (a.live ? a.live[r0 + r] != 0 : true);
+            const int lab = (row_ok && a.labels) ? a.labels[r0 + r] : -1;
+            float loss = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int j = sl + 8 * i;
+                if (j < Cp) {
+                    float d = 0.0f;
+                    if (row_ok && j < C) {
+                        const float o = v[i] / sum;
+                        const float tj = a.labels ? (j == lab ? 1.0f : 0.0f) : a.target[j];
+                        if (tj != 0.0f) loss -= tj * logf(fmaxf(o, 1e-12f));
+                        d = alive ? o - tj : 0.0f;
+                    }
+                    p[j] = d;
+                }
+            }
+            loss += __shfl_xor(loss, 4);
+            loss += __shfl_xor(loss, 2);
+            loss += __shfl_xor(loss, 1);
+            if (sl == 0 && alive) { loss_sum += (double)loss; live_sum += 1.0; }
+        }
+        __syncthreads();
+        // dW3[k][c] += sum_r h2[r][k] delta3[r][c]   (thread = k), db3 (threads 0..C-1)
+        if (tid < H2) {
+#pragma unroll 4
+            for (int r = 0; r < kHeadRows; ++r) {
+                const float h = H2s[r * LDH + tid];
+                const float* d = D3s + r * Cp;
+#pragma unroll
+                for (int cg = 0; cg < Cq; ++cg) {
+                    const float4 dv = *reinterpret_cast<const float4*>(d + 4 * cg);
+                    acc_w3[4 * cg + 0] += h * dv.x; acc_w3[4 * cg + 1] += h * dv.y;
+                    acc_w3[4 * cg + 2] += h * dv.z; acc_w3[4 * cg + 3] += h * dv.w;
+                }
+            }
+        }
+        if (tid < C) {
+            float sb = 0.0f;
+            for (int r = 0; r < kHeadRows; ++r) sb += D3s[r * Cp + tid];
+            acc_b3 += sb;
+        }
+        __syncthreads();
+        // delta2 in place: 4 hidden units of one row per work item
+        for (int o = tid; o < kHeadRows * (H2 / 4); o += kHeadThreads) {
+            const int r = o / (H2 / 4), jq = o - r * (H2 / 4);
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+            const float* d = D3s + r * Cp;
+#pragma unroll
+            for (int c = 0; c < CP; ++c) {  // padded classes carry delta3 = 0 and w3 = 0
+                const float dc = d[c];
+                const float4 w = *reinterpret_cast<const float4*>(W3T + c * LDH + 4 * jq);
+                s0 += dc * w.x; s1 += dc * w.y; s2 += dc * w.z; s3 += dc * w.w;
+            }
+            float4* hp = reinterpret_cast<float4*>(H2s + r * LDH + 4 * jq);
+            const float4 h = *hp;
+            *hp = make_float4(s0 * (1.0f - h.x * h.x), s1 * (1.0f - h.y * h.y), s2 * (1.0f - h.z * h.z),
+                              s3 * (1.0f - h.w * h.w));
+        }
+        __syncthreads();
+        // db2 and the coalesced store of delta2
+        if (tid < H2) {
+            float sb = 0.0f;
+            for (int r = 0; r < kHeadRows; ++r) sb += H2s[r * LDH + tid];
+            acc_b2 += sb;
+        }
+        for (int i = tid; i < nr * (H2 / 4); i += kHeadThreads) {
+            const int r = i / (H2 / 4), q = i - r * (H2 / 4);
+            *reinterpret_cast<float4*>(a.d2 + (r0 + r) * H2 + 4 * q) = *reinterpret_cast<const float4*>(H2s + r * LDH + 4 * q);
+        }
+    }
+    // gradient partials of this workgroup
+    float* sw = a.slab_w3 + (size_t)blockIdx.x * ((size_t)H2 * C + C);
+    if (tid < H2) {
+#pragma unroll
+        for (int c = 0; c < CP; ++c)
+            if (c < C) sw[(size_t)tid * C + c] = acc_w3[c];
+        a.slab_b2[(size_t)blockIdx.x * H2 + tid] = acc_b2;
+    }
+    if (tid < C) sw[(size_t)H2 * C + tid] = acc_b3;
+    // loss / live-row statistics: one atomic pair per workgroup
+    for (int off = 32; off > 0; off >>= 1) {
+        loss_sum += __shfl_down(loss_sum, off);
+        live_sum += __shfl_down(live_sum, off);
+    }
+    __shared__ double s_stat[8];  // 64 bytes: keeps the dynamic LDS base 16-byte aligned
+    if ((tid & 63) == 0) { s_stat[tid >> 6] = loss_sum; s_stat[4 + (tid >> 6)] = live_sum; }
+    __syncthreads();
+    if (tid == 0) {
+        const double ls = (s_stat[0] + s_stat[1]) + (s_stat[2] + s_stat[3]);
+        const double lv = (s_stat[4] + s_stat[5]) + (s_stat[6] + s_stat[7]);
+        if (lv > 0.0) {
+            atomicAdd(&a.stats[0], ls);
+            atomicAdd(&a.stats[1], lv);
+        }
+    }
+}
+
+// out[c][r] = in[r][c]; 32x32 tiles through LDS
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, int rows, int cols,
+                                                        float* __restrict__ out)
+{
+    __shared__ float t[32][33];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8)
+        if (r0 + i < rows && c0 + tx < cols) t[i][tx] = in[(size_t)(r0 + i) * cols + c0 + tx];
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8)
+        if (c0 + i < cols && r0 + tx < rows) out[(size_t)(c0 + i) * rows + r0 + tx] = t[tx][i];
+}
+
 // ---- column sums (bias gradients), split over rows into slabs ------------------------
 __global__ void colsum_kernel(const float* __restrict__ D, uint64_t rows, int cols, int ld, int rows_per_split,
                               float* __restrict__ slab)
@@ -330,14 +395,27 @@ __global__ void colsum_kernel(const float* __restrict__ D, uint64_t rows, int co
                                              (part[2][threadIdx.x] + part[3][threadIdx.x]);
 }
 
-// grad[i] += sum_z slab[z][i]
-__global__ void slab_reduce_kernel(const float* __restrict__ slab, int splits, uint64_t len, float* __restrict__ grad)
+// grad[i] += sum_z slab[z][i].  32 consecutive elements x 8 groups of slabs per workgroup; the
+// groups' partial sums are combined in a fixed order, so the result is reproducible.
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slab, int splits, uint64_t len,
+                                                          float* __restrict__ grad)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= len) return;
+    __shared__ float part[8][32];
+    const int c = threadIdx.x & 31, zg = threadIdx.x >> 5;
+    const uint64_t i = (uint64_t)blockIdx.x * 32 + c;
     float s = 0.0f;
-    for (int z = 0; z < splits; ++z) s += slab[(size_t)z * len + i];
-    grad[i] += s;
+    if (i < len) {
+#pragma unroll 4
+        for (int z = zg; z < splits; z += 8) s += slab[(size_t)z * len + i];
+    }
+    part[zg][c] = s;
+    __syncthreads();
+    if (zg == 0 && i < len) {
+        float t = part[0][c];
+#pragma unroll
+        for (int g = 1; g < 8; ++g) t += part[g][c];
+        grad[i] += t;
+    }
 }
 
 // stats = {loss, live rows} since the last zero_grad, then {loss, live rows} running totals
@@ -369,21 +447,22 @@ __global__ void apply_kernel(float* __restrict__ params, const float* __restrict
     if (i < n) params[i] -= grad[i] * scale;
 }
 
-constexpr uint64_t kChunkRows = 32768;
+// 49 152 rows = 768 block tiles of the large GEMMs = 3 per CU, all resident at once
+constexpr uint64_t kChunkRows = 49152;
 
 int ensure_workspace(Net* n, uint64_t rows)
 {
     Workspace& w = n->ws;
     if (rows > kChunkRows) rows = kChunkRows;
     if (w.rows >= rows && w.out == n->out) return SZH_OK;
-    float** ptrs[] = {&w.xd, &w.h1, &w.h2, &w.p, &w.d2, &w.d1, &w.slab};
+    float** ptrs[] = {&w.xd, &w.h1, &w.h2, &w.p, &w.d2, &w.d1, &w.slab, &w.w2t};
     for (float** p : ptrs) { if (*p) (void)hipFree(*p); *p = nullptr; }
     if (w.live) { (void)hipFree(w.live); w.live = nullptr; }
     w.rows = 0;
     const uint64_t R = rows < 256 ? 256 : rows;
-    const uint64_t maxw = std::max<uint64_t>({(uint64_t)n->in * n->h1, (uint64_t)n->h1 * n->h2,
-                                             (uint64_t)n->h2 * n->out, (uint64_t)n->h1});
-    w.slab_floats = 64 * maxw;
+    const uint64_t maxw = std::max<uint64_t>({(uint64_t)(n->in + 1) * n->h1, (uint64_t)(n->h1 + 1) * n->h2,
+                                             (uint64_t)(n->h2 + 1) * n->out, (uint64_t)n->h1});
+    w.slab_floats = std::max<uint64_t>(64 * maxw, 2048 * ((uint64_t)(n->h2 + 1) * n->out + n->h2));
     SZ_HIP(hipMalloc((void**)&w.xd, R * n->in * sizeof(float)));
     SZ_HIP(hipMalloc((void**)&w.h1, R * n->h1 * sizeof(float)));
     SZ_HIP(hipMalloc((void**)&w.h2, R * n->h2 * sizeof(float)));
@@ -392,6 +471,7 @@ int ensure_workspace(Net* n, uint64_t rows)
     SZ_HIP(hipMalloc((void**)&w.d1, R * n->h1 * sizeof(float)));
     SZ_HIP(hipMalloc((void**)&w.slab, w.slab_floats * sizeof(float)));
     SZ_HIP(hipMalloc((void**)&w.live, R));
+    SZ_HIP(hipMalloc((void**)&w.w2t, (uint64_t)n->h1 * n->h2 * sizeof(float)));
     w.rows = R;
     w.out = n->out;
     return SZH_OK;
@@ -424,9 +504,12 @@ int forward_logits(Net* n, uint64_t rows, float* out, hipStream_t s)
     return launch_gemm<A_ROWS, B_KROWS, EPI_BIAS, T_FWD3>(g, 1, s);
 }
 
+// grad[M][N] += A^T . B over `rows` rows, A = [rows][M], B = [rows][N].  With bias_row the
+// contraction is done for M + 1 rows, the extra one against a column of ones, which is the bias
+// gradient; it lands right behind the weight gradient, where the bias sits in the vector.
 template <int TAG>
 int grad_gemm(Net* n, const float* A, int lda, const float* B, int ldb, int M, int N, uint64_t rows, float* grad,
-              hipStream_t s)
+              bool bias_row, hipStream_t s)
 {
     Workspace& w = n->ws;
     int splits = (int)((rows + 511) / 512);
@@ -437,13 +520,14 @@ int grad_gemm(Net* n, const float* A, int lda, const float* B, int ldb, int M, i
     splits = (int)((rows + k_chunk - 1) / k_chunk);
     GemmArgs g{};
     g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = w.slab; g.ldc = N;
-    g.M = M; g.N = N; g.K = (int)rows; g.k_chunk = k_chunk;
+    g.M = bias_row ? M + 1 : M; g.N = N; g.K = (int)rows; g.k_chunk = k_chunk;
+    g.ones_row = bias_row ? M : -1;
     int rc = launch_gemm<A_KROWS, B_KROWS, EPI_SLAB, TAG>(g, splits, s);
     if (rc) return rc;
-    const uint64_t len = (uint64_t)M * N;
+    const uint64_t len = (uint64_t)g.M * N;
     {
         ProfScope prof("reduce", s);
-        hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, s, w.slab, splits,
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((len + 31) / 32)), dim3(256), 0, s, w.slab, splits,
                            len, grad);
     }
     SZ_HIP(hipGetLastError());
@@ -462,7 +546,7 @@ int grad_bias(Net* n, const float* D, int cols, uint64_t rows, float* grad, hipS
         ProfScope prof("bias", s);
         hipLaunchKernelGGL(colsum_kernel, dim3((cols + 63) / 64, splits), dim3(256), 0, s, D, rows, cols, cols, rps,
                            w.slab);
-        hipLaunchKernelGGL(slab_reduce_kernel, dim3((cols + 255) / 256), dim3(256), 0, s, w.slab, splits,
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3((cols + 31) / 32), dim3(256), 0, s, w.slab, splits,
                            (uint64_t)cols, grad);
     }
     SZ_HIP(hipGetLastError());
@@ -509,7 +593,7 @@ void net_destroy(Net* n)
 {
     if (!n) return;
     Workspace& w = n->ws;
-    float* ptrs[] = {w.xd, w.h1, w.h2, w.p, w.d2, w.d1, w.slab, n->d_params, n->d_grad};
+    float* ptrs[] = {w.xd, w.h1, w.h2, w.p, w.d2, w.d1, w.slab, w.w2t, n->d_params, n->d_grad};
     for (float* p : ptrs) if (p) (void)hipFree(p);
     if (w.live) (void)hipFree(w.live);
     if (n->d_stats) (void)hipFree(n->d_stats);
@@ -618,6 +702,13 @@ int net_accumulate(Net* n, const AccumArgs& a, hipStream_t s)
     Workspace& w = n->ws;
     const float* P = n->d_params;
     float* G = n->d_grad;
+    {   // w2 transposed once per call (the weights are frozen while gradients accumulate), so that
+        // delta1 = delta2 . w2^T reads its second operand k-major like the forward product does
+        ProfScope prof("w2t", s);
+        hipLaunchKernelGGL(transpose_kernel, dim3((n->h2 + 31) / 32, (n->h1 + 31) / 32), dim3(256), 0, s,
+                           P + n->off_w2(), (int)n->h1, (int)n->h2, w.w2t);
+    }
+    SZ_HIP(hipGetLastError());
     for (uint64_t r0 = 0; r0 < a.rows; r0 += kChunkRows) {
         const uint64_t R = std::min<uint64_t>(kChunkRows, a.rows - r0);
         // gather / dropout / live flags
@@ -631,39 +722,78 @@ int net_accumulate(Net* n, const AccumArgs& a, hipStream_t s)
         SZ_HIP(hipGetLastError());
         rc = forward_hidden(n, w.xd, R, false, s);
         if (rc) return rc;
-        rc = forward_logits(n, R, w.p, s);
-        if (rc) return rc;
-        {
-            ProfScope prof("softmax", s);
-            hipLaunchKernelGGL(softmax_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s, w.p, R, (int)n->out,
-                               1, a.target_dev, a.labels_dev ? a.labels_dev + r0 : nullptr, (const uint8_t*)w.live,
-                               n->d_stats);
+        const bool use_head = n->out <= 32 && n->h2 <= 256 && (n->h2 % 4) == 0;
+        if (use_head) {
+            HeadArgs h{};
+            h.h2 = w.h2; h.w3 = P + n->off_w3(); h.b3 = P + n->off_b3();
+            h.target = a.target_dev; h.labels = a.labels_dev ? a.labels_dev + r0 : nullptr; h.live = w.live;
+            h.d2 = w.d2; h.stats = n->d_stats; h.rows = R; h.H2 = (int)n->h2; h.C = (int)n->out;
+            h.Cp = n->out <= 4 ? 4 : (n->out <= 8 ? 8 : (n->out <= 16 ? 16 : 32));
+            const int tiles = (int)((R + kHeadRows - 1) / kHeadRows);
+            int blocks = tiles < 2048 ? tiles : 2048;
+            h.tiles_per_block = (tiles + blocks - 1) / blocks;
+            blocks = (tiles + h.tiles_per_block - 1) / h.tiles_per_block;
+            const uint64_t len3 = (uint64_t)n->h2 * n->out + n->out;
+            h.slab_w3 = w.slab;
+            h.slab_b2 = w.slab + (size_t)blocks * len3;
+            const int ldh = (int)n->h2 + 4;
+            const size_t lds = sizeof(float) * ((size_t)kHeadRows * ldh + (size_t)n->h2 * h.Cp + (size_t)h.Cp * ldh +
+                                                (size_t)kHeadRows * h.Cp);
+            static bool attr_set = false;
+            if (!attr_set) {
+                const void* fns[] = {(const void*)head_kernel<4>, (const void*)head_kernel<8>,
+                                     (const void*)head_kernel<16>, (const void*)head_kernel<32>};
+                for (const void* fn : fns)
+                    SZ_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024));
+                attr_set = true;
+            }
+            {
+                ProfScope prof("head", s);
+                if (h.Cp <= 4) { h.Cp = 4; hipLaunchKernelGGL(head_kernel<4>, dim3(blocks), dim3(kHeadThreads), lds, s, h); }
+                else if (h.Cp <= 8) { h.Cp = 8; hipLaunchKernelGGL(head_kernel<8>, dim3(blocks), dim3(kHeadThreads), lds, s, h); }
+                else if (h.Cp <= 16) { h.Cp = 16; hipLaunchKernelGGL(head_kernel<16>, dim3(blocks), dim3(kHeadThreads), lds, s, h); }
+                else { h.Cp = 32; hipLaunchKernelGGL(head_kernel<32>, dim3(blocks), dim3(kHeadThreads), lds, s, h); }
+            }
+            SZ_HIP(hipGetLastError());
+            {
+                ProfScope prof("reduce", s);
+                hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((len3 + 31) / 32)), dim3(256), 0, s,
+                                   (const float*)h.slab_w3, blocks, len3, G + n->off_w3());
+                hipLaunchKernelGGL(slab_reduce_kernel, dim3((n->h2 + 31) / 32), dim3(256), 0, s,
+                                   (const float*)h.slab_b2, blocks, (uint64_t)n->h2, G + n->off_b2());
+            }
+            SZ_HIP(hipGetLastError());
+        } else {
+            rc = forward_logits(n, R, w.p, s);
+            if (rc) return rc;
+            {
+                ProfScope prof("softmax", s);
+                hipLaunchKernelGGL(softmax_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s, w.p, R,
+                                   (int)n->out, 1, a.target_dev, a.labels_dev ? a.labels_dev + r0 : nullptr,
+                                   (const uint8_t*)w.live, n->d_stats);
+            }
+            SZ_HIP(hipGetLastError());
+            // delta2 = (delta3 . w3^T) * (1 - h2^2)
+            GemmArgs g{};
+            g.A = w.p; g.lda = n->out; g.B = P + n->off_w3(); g.ldb = n->out; g.C = w.d2; g.ldc = n->h2;
+            g.M = (int)R; g.N = n->h2; g.K = n->out; g.k_chunk = n->out; g.aux = w.h2; g.ldaux = n->h2;
+            rc = launch_gemm<A_ROWS, B_ROWS, EPI_MUL_DTANH, T_DELTA2>(g, 1, s);
+            if (rc) return rc;
+            rc = grad_gemm<T_DW3>(n, w.h2, n->h2, w.p, n->out, n->h2, n->out, R, G + n->off_w3(), true, s);
+            if (rc) return rc;
+            rc = grad_bias(n, w.d2, n->h2, R, G + n->off_b2(), s);
+            if (rc) return rc;
         }
-        SZ_HIP(hipGetLastError());
-        // delta2 = (delta3 . w3^T) * (1 - h2^2)
-        GemmArgs g{};
-        g.A = w.p; g.lda = n->out; g.B = P + n->off_w3(); g.ldb = n->out; g.C = w.d2; g.ldc = n->h2;
-        g.M = (int)R; g.N = n->h2; g.K = n->out; g.k_chunk = n->out; g.aux = w.h2; g.ldaux = n->h2;
-        rc = launch_gemm<A_ROWS, B_ROWS, EPI_MUL_DTANH, T_DELTA2>(g, 1, s);
-        if (rc) return rc;
         // delta1 = (delta2 . w2^T) * [h1 > 0]
-        g = GemmArgs{};
-        g.A = w.d2; g.lda = n->h2; g.B = P + n->off_w2(); g.ldb = n->h2; g.C = w.d1; g.ldc = n->h1;
+        GemmArgs g{};
+        g.A = w.d2; g.lda = n->h2; g.B = w.w2t; g.ldb = n->h1; g.C = w.d1; g.ldc = n->h1;
         g.M = (int)R; g.N = n->h1; g.K = n->h2; g.k_chunk = n->h2; g.aux = w.h1; g.ldaux = n->h1;
-        rc = launch_gemm<A_ROWS, B_ROWS, EPI_MUL_DRELU, T_DELTA1>(g, 1, s);
+        rc = launch_gemm<A_ROWS, B_KROWS, EPI_MUL_DRELU, T_DELTA1>(g, 1, s);
         if (rc) return rc;
-        // weight gradients: contractions over the rows
-        rc = grad_gemm<T_DW3>(n, w.h2, n->h2, w.p, n->out, n->h2, n->out, R, G + n->off_w3(), s);
+        // weight gradients: contractions over the rows ([w1|b1] in one launch via the ones row)
+        rc = grad_gemm<T_DW2>(n, w.h1, n->h1, w.d2, n->h2, n->h1, n->h2, R, G + n->off_w2(), false, s);
         if (rc) return rc;
-        rc = grad_bias(n, w.p, n->out, R, G + n->off_b3(), s);
-        if (rc) return rc;
-        rc = grad_gemm<T_DW2>(n, w.h1, n->h1, w.d2, n->h2, n->h1, n->h2, R, G + n->off_w2(), s);
-        if (rc) return rc;
-        rc = grad_bias(n, w.d2, n->h2, R, G + n->off_b2(), s);
-        if (rc) return rc;
-        rc = grad_gemm<T_DW1>(n, w.xd, n->in, w.d1, n->h1, n->in, n->h1, R, G + n->off_w1(), s);
-        if (rc) return rc;
-        rc = grad_bias(n, w.d1, n->h1, R, G + n->off_b1(), s);
+        rc = grad_gemm<T_DW1>(n, w.xd, n->in, w.d1, n->h1, n->in, n->h1, R, G + n->off_w1(), true, s);
         if (rc) return rc;
     }
     hipLaunchKernelGGL(stats_to_tail_kernel, dim3(1), dim3(64), 0, s, n->d_stats, G + n->param_count());
