@@ -28,7 +28,7 @@ enum Epi {
     EPI_BIAS = 2,       // C = acc + bias[n]
     EPI_MUL_DTANH = 3,  // C = acc * (1 - aux^2)          (lib.rs:1034)
     EPI_MUL_DRELU = 4,  // C = acc * (aux > 0)            (lib.rs:1039-1040)
-    EPI_SLAB = 5        // C[z] = acc                     (split-K partial)
+    EPI_SLAB = 5        // C[z] (+)= acc                  (split-K partial)
 };
 
 struct GemmArgs {
@@ -43,6 +43,7 @@ struct GemmArgs {
     int k_chunk;   // K range handled by one blockIdx.z
     int a_vec, b_vec;
     int ones_row = -1;  // A_KROWS only: logical row M-1 of A is all ones (bias-gradient row)
+    int slab_add = 0;   // EPI_SLAB only: add to the slab instead of overwriting it
 };
 
 struct Frag4 { float v[4]; };
@@ -157,6 +158,10 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_kernel(GemmArgs g)
     const int l31 = lane & 31, half = lane >> 5;
     const int a_cols = g.ones_row >= 0 ? g.M - 1 : g.M;  // columns of A that exist in memory (A_KROWS)
 
+    float* C = g.C;
+    if (EPI == EPI_SLAB) C += (size_t)blockIdx.z * (size_t)g.M * (size_t)g.ldc;
+    // Accumulators start at zero, or, for a split-K slab that is being added to, at the slab's
+    // current contents: those loads overlap the first operand fetch.
     f32x16 acc[2][TN];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -164,6 +169,19 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_kernel(GemmArgs g)
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    if (EPI == EPI_SLAB && g.slab_add) {
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                const int col = n0 + wn * WN + tn * 32 + l31;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (col < g.N && row < g.M) acc[tm][tn][r] = C[(size_t)row * g.ldc + col];
+                }
+            }
+    }
 
     Frag4 fa[TM * BK / 1024], fb[BN * BK / 1024];
     // interior tiles (the common case) take straight-line 16-byte loads; edge tiles are guarded
@@ -232,8 +250,6 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_kernel(GemmArgs g)
         }
     }
 
-    float* C = g.C;
-    if (EPI == EPI_SLAB) C += (size_t)blockIdx.z * (size_t)g.M * (size_t)g.ldc;
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm)
 #pragma unroll

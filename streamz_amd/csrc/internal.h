@@ -61,6 +61,8 @@ struct Workspace {
           *w2t = nullptr;
     uint8_t* live = nullptr;
     uint64_t slab_floats = 0;
+    // regions of `slab` (float offsets): split-K partials of dW1|db1, dW2, dW3|db3 and db2
+    uint64_t sl_w1 = 0, sl_w2 = 0, sl_w3 = 0, sl_b2 = 0;
 };
 
 struct Net {

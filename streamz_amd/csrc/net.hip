@@ -182,6 +182,7 @@ struct HeadArgs {
     uint64_t rows;
     int H2, C, Cp;         // Cp = C rounded up to a multiple of 4
     int tiles_per_block;
+    int add;               // add to the slabs instead of overwriting them
 };
 
 template <int CP>
@@ -340,10 +341,11 @@ __global__ __launch_bounds__(kHeadThreads) void head_kernel(HeadArgs a)
     if (tid < H2) {
 #pragma unroll
         for (int c = 0; c < CP; ++c)
-            if (c < C) sw[(size_t)tid * C + c] = acc_w3[c];
-        a.slab_b2[(size_t)blockIdx.x * H2 + tid] = acc_b2;
+            if (c < C) sw[(size_t)tid * C + c] = (a.add ? sw[(size_t)tid * C + c] : 0.0f) + acc_w3[c];
+        float* sb = a.slab_b2 + (size_t)blockIdx.x * H2 + tid;
+        *sb = (a.add ? *sb : 0.0f) + acc_b2;
     }
-    if (tid < C) sw[(size_t)H2 * C + tid] = acc_b3;
+    if (tid < C) sw[(size_t)H2 * C + tid] = (a.add ? sw[(size_t)H2 * C + tid] : 0.0f) + acc_b3;
     // loss / live-row statistics: one atomic pair per workgroup
     for (int off = 32; off > 0; off >>= 1) {
         loss_sum += __shfl_down(loss_sum, off);
@@ -351,6 +353,202 @@ __global__ __launch_bounds__(kHeadThreads) void head_kernel(HeadArgs a)
     }
     __shared__ double s_stat[8];  // 64 bytes: keeps the dynamic LDS base 16-byte aligned
     if ((tid & 63) == 0) { s_stat[tid >> 6] = loss_sum; s_stat[4 + (tid >> 6)] = live_sum; }
+    __syncthreads();
+    if (tid == 0) {
+        const double ls = (s_stat[0] + s_stat[1]) + (s_stat[2] + s_stat[3]);
+        const double lv = (s_stat[4] + s_stat[5]) + (s_stat[6] + s_stat[7]);
+        if (lv > 0.0) {
+            atomicAdd(&a.stats[0], ls);
+            atomicAdd(&a.stats[1], lv);
+        }
+    }
+}
+
+// ---- output head on the matrix cores, for C <= 16 and hidden2 = 16 KB (KB = 4, 8 or 16) -------
+// One wave owns a tile of 16 rows; v_mfma_f32_16x16x4_f32 throughout.  With lane = (m, g),
+// m = lane % 16, g = lane / 16, an A operand is A[m][4g+s], a B operand is B[4g+s][m] and a
+// result register v is D[4g+v][m] (s, v = 0..3; the contraction index of step s is 4g+s on both
+// sides, which is all the instruction needs).  Hence
+//   logits[row 4g+v][class m]   = sum_k  h2[row m][k] . w3[k][class m]           (A = h2, B = w3)
+//   delta3 = softmax - target, kept as D and reused directly as a B operand whose contraction
+//            index is the row:  dW3[k][class m] += sum_rows h2t[k][row] . delta3[row][class m]
+//   h2t (rows in the g part) and delta3^T come from multiplying by an identity operand, which
+//            moves a 16x16 block from the A layout to the D layout exactly,
+//   delta2^T[k][row m] = sum_c w3[k][c] . delta3^T[c][row m], times 1 - h2^2 (lib.rs:1034),
+//            stored as 16-byte pieces of delta2[row m][k..k+3].
+// w3 sits in LDS in both operand layouts; the gradient partials of the 4 waves are summed in a
+// fixed order and go to the slab of this workgroup.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int kMHeadBlocks = 512;
+
+#define SZ_MFMA16(a_, b_, c_) __builtin_amdgcn_mfma_f32_16x16x4f32((a_), (b_), (c_), 0, 0, 0)
+
+template <int KB>
+__global__ __launch_bounds__(256, 2) void head_mfma_kernel(HeadArgs a)
+{
+    constexpr int H2 = KB * 16;
+    __shared__ __attribute__((aligned(16))) float tab[2 * KB * 64 * 4];
+    float4* Wb = reinterpret_cast<float4*>(tab);  // [KB][lane]: w3[16j + 4g + s][m], s = x..w
+    float4* Wa = Wb + KB * 64;                    // [KB][lane]: w3[16j + m][4g + i], i = x..w
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, m = lane & 15, g = lane >> 4;
+    const int C = a.C;
+    for (int e = tid; e < KB * 64; e += 256) {
+        const int j = e >> 6, mm = e & 15, gg = (e & 63) >> 4;
+        float t[4], u[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            t[q] = mm < C ? a.w3[(size_t)(16 * j + 4 * gg + q) * C + mm] : 0.0f;
+            u[q] = 4 * gg + q < C ? a.w3[(size_t)(16 * j + mm) * C + 4 * gg + q] : 0.0f;
+        }
+        Wb[e] = make_float4(t[0], t[1], t[2], t[3]);
+        Wa[e] = make_float4(u[0], u[1], u[2], u[3]);
+    }
+    __syncthreads();
+    const bool cls = m < C;
+    const float b3m = cls ? a.b3[m] : 0.0f;
+    const float tgt_m = (a.target && cls) ? a.target[m] : 0.0f;
+    f32x4 ident;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) ident[q] = (4 * g + q == m) ? 1.0f : 0.0f;
+    f32x4 acc3[KB];
+    float accb2[KB];  // db2[16j + m], rows of group g only
+#pragma unroll
+    for (int j = 0; j < KB; ++j) {
+        accb2[j] = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc3[j][q] = 0.0f;
+    }
+    float accb3 = 0.0f;
+    double loss_sum = 0.0, live_sum = 0.0;
+
+    const uint64_t tiles = (a.rows + 15) / 16;
+    for (uint64_t t = (uint64_t)blockIdx.x * 4 + wave; t < tiles; t += (uint64_t)gridDim.x * 4) {
+        const uint64_t r0 = t * 16, rm = r0 + m;
+        const bool okm = rm < a.rows;
+        const float* hrow = a.h2 + rm * H2 + 4 * g;
+        float4 Ha[KB];
+#pragma unroll
+        for (int j = 0; j < KB; ++j)
+            Ha[j] = okm ? *reinterpret_cast<const float4*>(hrow + 16 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
+        f32x4 L = {0.f, 0.f, 0.f, 0.f};
+        // The scheduling barriers keep the compiler from hoisting every operand read of the
+        // unrolled loops to the top, which would need far more registers than there are.
+        float4 wb_next = Wb[lane];
+#pragma unroll
+        for (int j = 0; j < KB; ++j) {
+            const float4 wb = wb_next;
+            if (j + 1 < KB) wb_next = Wb[(j + 1) * 64 + lane];
+            L = SZ_MFMA16(Ha[j].x, wb.x, L);
+            L = SZ_MFMA16(Ha[j].y, wb.y, L);
+            L = SZ_MFMA16(Ha[j].z, wb.z, L);
+            L = SZ_MFMA16(Ha[j].w, wb.w, L);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // softmax over the 16 lanes that share g; loss and delta3 (lib.rs:1022-1028)
+        f32x4 d3;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const uint64_t rv = r0 + 4 * g + v;
+            const bool okv = rv < a.rows;
+            const float x = cls ? L[v] + b3m : -INFINITY;
+            float mx = x;
+            mx = fmaxf(mx, __shfl_xor(mx, 1));
+            mx = fmaxf(mx, __shfl_xor(mx, 2));
+            mx = fmaxf(mx, __shfl_xor(mx, 4));
+            mx = fmaxf(mx, __shfl_xor(mx, 8));
+            const float e = cls ? expf(x - mx) : 0.0f;
+            float sum = e;
+            sum += __shfl_xor(sum, 1);
+            sum += __shfl_xor(sum, 2);
+            sum += __shfl_xor(sum, 4);
+            sum += __shfl_xor(sum, 8);
+            const float o = e / sum;
+            const bool alive = okv && (a.live ? a.live[rv] != 0 : true);
+            const int lab = (okv && a.labels) ? a.labels[rv] : -1;
+            const float tj = a.labels ? (m == lab ? 1.0f : 0.0f) : tgt_m;
+            float d = 0.0f;
+            if (alive && cls) {
+                if (tj != 0.0f) loss_sum -= (double)(tj * logf(fmaxf(o, 1e-12f)));
+                d = o - tj;
+            }
+            if (alive && m == 0) live_sum += 1.0;
+            d3[v] = d;
+            accb3 += d;
+        }
+        f32x4 d3t = {0.f, 0.f, 0.f, 0.f};  // delta3[row m][class 4g+v]
+#pragma unroll
+        for (int v = 0; v < 4; ++v) d3t = SZ_MFMA16(d3[v], ident[v], d3t);
+        float4 wa_next = Wa[lane];
+#pragma unroll
+        for (int j = 0; j < KB; ++j) {
+            const float4 h = Ha[j];
+            const float4 wa = wa_next;
+            if (j + 1 < KB) wa_next = Wa[(j + 1) * 64 + lane];
+            f32x4 hb = {0.f, 0.f, 0.f, 0.f};  // h2[row 4g+v][16j + m]
+            hb = SZ_MFMA16(h.x, ident[0], hb);
+            hb = SZ_MFMA16(h.y, ident[1], hb);
+            hb = SZ_MFMA16(h.z, ident[2], hb);
+            hb = SZ_MFMA16(h.w, ident[3], hb);
+            f32x4 q = {0.f, 0.f, 0.f, 0.f};   // (delta3 . w3^T)[row m][16j + 4g + v]
+            q = SZ_MFMA16(wa.x, d3t[0], q);
+            q = SZ_MFMA16(wa.y, d3t[1], q);
+            q = SZ_MFMA16(wa.z, d3t[2], q);
+            q = SZ_MFMA16(wa.w, d3t[3], q);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) acc3[j] = SZ_MFMA16(hb[v], d3[v], acc3[j]);
+            const float4 o = make_float4(q[0] * (1.0f - h.x * h.x), q[1] * (1.0f - h.y * h.y),
+                                         q[2] * (1.0f - h.z * h.z), q[3] * (1.0f - h.w * h.w));
+            // row sums for db2 (lib.rs:1038): the identity product moves the block to [row 4g+v][k = m]
+            f32x4 ot = {0.f, 0.f, 0.f, 0.f};
+            ot = SZ_MFMA16(o.x, ident[0], ot);
+            ot = SZ_MFMA16(o.y, ident[1], ot);
+            ot = SZ_MFMA16(o.z, ident[2], ot);
+            ot = SZ_MFMA16(o.w, ident[3], ot);
+            accb2[j] += (ot[0] + ot[1]) + (ot[2] + ot[3]);
+            if (okm) *reinterpret_cast<float4*>(a.d2 + rm * H2 + 16 * j + 4 * g) = o;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+    // sums over the rows held by different lane groups
+#pragma unroll
+    for (int j = 0; j < KB; ++j) {
+        accb2[j] += __shfl_xor(accb2[j], 16);
+        accb2[j] += __shfl_xor(accb2[j], 32);
+    }
+    accb3 += __shfl_xor(accb3, 16);
+    accb3 += __shfl_xor(accb3, 32);
+    __syncthreads();  // every wave is done with the w3 tables; their LDS now holds the sums
+    float* red = tab;                         // [H2*C + C] (dW3 then db3), then [H2] (db2)
+    const int len3 = H2 * C + C;
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int j = 0; j < KB; ++j)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int k = 16 * j + 4 * g + v;
+                    if (cls) red[k * C + m] = (w ? red[k * C + m] : 0.0f) + acc3[j][v];
+                }
+            if (g == 0) {
+#pragma unroll
+                for (int j = 0; j < KB; ++j) red[len3 + 16 * j + m] = (w ? red[len3 + 16 * j + m] : 0.0f) + accb2[j];
+                if (cls) red[H2 * C + m] = (w ? red[H2 * C + m] : 0.0f) + accb3;
+            }
+        }
+        __syncthreads();
+    }
+    float* sw = a.slab_w3 + (size_t)blockIdx.x * len3;
+    for (int i = tid; i < len3; i += 256) sw[i] = (a.add ? sw[i] : 0.0f) + red[i];
+    float* sb = a.slab_b2 + (size_t)blockIdx.x * H2;
+    for (int i = tid; i < H2; i += 256) sb[i] = (a.add ? sb[i] : 0.0f) + red[len3 + i];
+
+    for (int off = 32; off > 0; off >>= 1) {
+        loss_sum += __shfl_down(loss_sum, off);
+        live_sum += __shfl_down(live_sum, off);
+    }
+    __shared__ double s_stat[8];
+    if (lane == 0) { s_stat[wave] = loss_sum; s_stat[4 + wave] = live_sum; }
     __syncthreads();
     if (tid == 0) {
         const double ls = (s_stat[0] + s_stat[1]) + (s_stat[2] + s_stat[3]);
@@ -378,7 +576,7 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
 
 // ---- column sums (bias gradients), split over rows into slabs ------------------------
 __global__ void colsum_kernel(const float* __restrict__ D, uint64_t rows, int cols, int ld, int rows_per_split,
-                              float* __restrict__ slab)
+                              int add, float* __restrict__ slab)
 {
     __shared__ float part[4][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
@@ -390,31 +588,47 @@ __global__ void colsum_kernel(const float* __restrict__ D, uint64_t rows, int co
         for (uint64_t r = r0 + rg; r < r1; r += 4) s += D[r * ld + c];
     part[rg][threadIdx.x & 63] = s;
     __syncthreads();
-    if (rg == 0 && c < cols)
-        slab[(size_t)blockIdx.y * cols + c] = (part[0][threadIdx.x] + part[1][threadIdx.x]) +
-                                             (part[2][threadIdx.x] + part[3][threadIdx.x]);
+    if (rg == 0 && c < cols) {
+        float* p = slab + (size_t)blockIdx.y * cols + c;
+        *p = (add ? *p : 0.0f) + ((part[0][threadIdx.x] + part[1][threadIdx.x]) +
+                                  (part[2][threadIdx.x] + part[3][threadIdx.x]));
+    }
 }
 
-// grad[i] += sum_z slab[z][i].  32 consecutive elements x 8 groups of slabs per workgroup; the
-// groups' partial sums are combined in a fixed order, so the result is reproducible.
+// grad[i] += sum_z slab[z][i].  128 consecutive elements (32 lanes x 4) x 8 groups of slabs per
+// workgroup; the groups' partial sums are combined in a fixed order, so the result is reproducible.
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slab, int splits, uint64_t len,
                                                           float* __restrict__ grad)
 {
-    __shared__ float part[8][32];
+    __shared__ float part[8][128];
     const int c = threadIdx.x & 31, zg = threadIdx.x >> 5;
-    const uint64_t i = (uint64_t)blockIdx.x * 32 + c;
-    float s = 0.0f;
-    if (i < len) {
+    const uint64_t i = (uint64_t)blockIdx.x * 128 + 4 * c;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if ((len & 3) == 0 && i + 3 < len) {
 #pragma unroll 4
-        for (int z = zg; z < splits; z += 8) s += slab[(size_t)z * len + i];
+        for (int z = zg; z < splits; z += 8) {
+            const float4 v = *reinterpret_cast<const float4*>(slab + (size_t)z * len + i);
+            s0 += v.x; s1 += v.y; s2 += v.z; s3 += v.w;
+        }
+    } else {
+        for (int z = zg; z < splits; z += 8) {
+            const float* p = slab + (size_t)z * len + i;
+            if (i < len) s0 += p[0];
+            if (i + 1 < len) s1 += p[1];
+            if (i + 2 < len) s2 += p[2];
+            if (i + 3 < len) s3 += p[3];
+        }
     }
-    part[zg][c] = s;
+    part[zg][4 * c] = s0; part[zg][4 * c + 1] = s1; part[zg][4 * c + 2] = s2; part[zg][4 * c + 3] = s3;
     __syncthreads();
-    if (zg == 0 && i < len) {
-        float t = part[0][c];
+    if (threadIdx.x < 128) {
+        const uint64_t o = (uint64_t)blockIdx.x * 128 + threadIdx.x;
+        if (o < len) {
+            float t = part[0][threadIdx.x];
 #pragma unroll
-        for (int g = 1; g < 8; ++g) t += part[g][c];
-        grad[i] += t;
+            for (int g = 1; g < 8; ++g) t += part[g][threadIdx.x];
+            grad[o] += t;
+        }
     }
 }
 
@@ -449,6 +663,7 @@ __global__ void apply_kernel(float* __restrict__ params, const float* __restrict
 
 // 49 152 rows = 768 block tiles of the large GEMMs = 3 per CU, all resident at once
 constexpr uint64_t kChunkRows = 49152;
+constexpr uint64_t kMaxSplits = 64;  // split-K slabs of a weight-gradient product
 
 int ensure_workspace(Net* n, uint64_t rows)
 {
@@ -460,9 +675,14 @@ int ensure_workspace(Net* n, uint64_t rows)
     if (w.live) { (void)hipFree(w.live); w.live = nullptr; }
     w.rows = 0;
     const uint64_t R = rows < 256 ? 256 : rows;
-    const uint64_t maxw = std::max<uint64_t>({(uint64_t)(n->in + 1) * n->h1, (uint64_t)(n->h1 + 1) * n->h2,
-                                             (uint64_t)(n->h2 + 1) * n->out, (uint64_t)n->h1});
-    w.slab_floats = std::max<uint64_t>(64 * maxw, 2048 * ((uint64_t)(n->h2 + 1) * n->out + n->h2));
+    // split-K partials live in four regions so that they can accumulate over the chunks of a call
+    const uint64_t head_blocks = 2048;  // upper bound of either head kernel's grid
+    const uint64_t len3 = (uint64_t)(n->h2 + 1) * n->out;
+    w.sl_w1 = 0;
+    w.sl_w2 = w.sl_w1 + kMaxSplits * (uint64_t)(n->in + 1) * n->h1;
+    w.sl_w3 = w.sl_w2 + kMaxSplits * (uint64_t)n->h1 * n->h2;
+    w.sl_b2 = w.sl_w3 + std::max<uint64_t>(kMaxSplits, head_blocks) * len3;
+    w.slab_floats = w.sl_b2 + std::max<uint64_t>(kMaxSplits, head_blocks) * n->h2;
     SZ_HIP(hipMalloc((void**)&w.xd, R * n->in * sizeof(float)));
     SZ_HIP(hipMalloc((void**)&w.h1, R * n->h1 * sizeof(float)));
     SZ_HIP(hipMalloc((void**)&w.h2, R * n->h2 * sizeof(float)));
@@ -504,51 +724,49 @@ int forward_logits(Net* n, uint64_t rows, float* out, hipStream_t s)
     return launch_gemm<A_ROWS, B_KROWS, EPI_BIAS, T_FWD3>(g, 1, s);
 }
 
-// grad[M][N] += A^T . B over `rows` rows, A = [rows][M], B = [rows][N].  With bias_row the
-// contraction is done for M + 1 rows, the extra one against a column of ones, which is the bias
-// gradient; it lands right behind the weight gradient, where the bias sits in the vector.
-template <int TAG>
-int grad_gemm(Net* n, const float* A, int lda, const float* B, int ldb, int M, int N, uint64_t rows, float* grad,
-              bool bias_row, hipStream_t s)
+// How the rows of one net_accumulate call are split into K ranges of the weight-gradient
+// products.  Fixed by the first (largest) chunk, so every chunk adds into the same slabs.
+struct SplitPlan { int k_chunk; int splits; };
+SplitPlan plan_splits(uint64_t rows0)
 {
-    Workspace& w = n->ws;
-    int splits = (int)((rows + 511) / 512);
-    if (splits > 64) splits = 64;
+    int splits = (int)((rows0 + 511) / 512);
+    if (splits > (int)kMaxSplits) splits = (int)kMaxSplits;
     if (splits < 1) splits = 1;
-    int k_chunk = (int)((rows + splits - 1) / splits);
+    int k_chunk = (int)((rows0 + splits - 1) / splits);
     k_chunk = (k_chunk + BK - 1) / BK * BK;
-    splits = (int)((rows + k_chunk - 1) / k_chunk);
+    return {k_chunk, (int)((rows0 + k_chunk - 1) / k_chunk)};
+}
+
+// slab[z][M][N] (+)= A^T . B over the K range z of `rows` rows, A = [rows][M], B = [rows][N].
+// With bias_row the contraction is done for M + 1 rows, the extra one against a column of ones,
+// which is the bias gradient; it lands right behind the weight gradient, where the bias sits in
+// the parameter vector.
+template <int TAG>
+int grad_gemm(const float* A, int lda, const float* B, int ldb, int M, int N, uint64_t rows, float* slab,
+              const SplitPlan& sp, bool add, bool bias_row, hipStream_t s)
+{
     GemmArgs g{};
-    g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = w.slab; g.ldc = N;
-    g.M = bias_row ? M + 1 : M; g.N = N; g.K = (int)rows; g.k_chunk = k_chunk;
+    g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = slab; g.ldc = N;
+    g.M = bias_row ? M + 1 : M; g.N = N; g.K = (int)rows; g.k_chunk = sp.k_chunk;
     g.ones_row = bias_row ? M : -1;
-    int rc = launch_gemm<A_KROWS, B_KROWS, EPI_SLAB, TAG>(g, splits, s);
-    if (rc) return rc;
-    const uint64_t len = (uint64_t)g.M * N;
-    {
-        ProfScope prof("reduce", s);
-        hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((len + 31) / 32)), dim3(256), 0, s, w.slab, splits,
-                           len, grad);
-    }
+    g.slab_add = add ? 1 : 0;
+    return launch_gemm<A_KROWS, B_KROWS, EPI_SLAB, TAG>(g, (int)((rows + sp.k_chunk - 1) / sp.k_chunk), s);
+}
+
+int reduce_slabs(const float* slab, int splits, uint64_t len, float* grad, hipStream_t s)
+{
+    ProfScope prof("reduce", s);
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((len + 127) / 128)), dim3(256), 0, s, slab, splits, len,
+                       grad);
     SZ_HIP(hipGetLastError());
     return SZH_OK;
 }
 
-int grad_bias(Net* n, const float* D, int cols, uint64_t rows, float* grad, hipStream_t s)
+int colsum_slabs(const float* D, int cols, uint64_t rows, float* slab, const SplitPlan& sp, bool add, hipStream_t s)
 {
-    Workspace& w = n->ws;
-    int splits = (int)((rows + 511) / 512);
-    if (splits > 64) splits = 64;
-    if (splits < 1) splits = 1;
-    const int rps = (int)((rows + splits - 1) / splits);
-    splits = (int)((rows + rps - 1) / rps);
-    {
-        ProfScope prof("bias", s);
-        hipLaunchKernelGGL(colsum_kernel, dim3((cols + 63) / 64, splits), dim3(256), 0, s, D, rows, cols, cols, rps,
-                           w.slab);
-        hipLaunchKernelGGL(slab_reduce_kernel, dim3((cols + 31) / 32), dim3(256), 0, s, w.slab, splits,
-                           (uint64_t)cols, grad);
-    }
+    ProfScope prof("bias", s);
+    hipLaunchKernelGGL(colsum_kernel, dim3((cols + 63) / 64, (unsigned)((rows + sp.k_chunk - 1) / sp.k_chunk)),
+                       dim3(256), 0, s, D, rows, cols, cols, sp.k_chunk, add ? 1 : 0, slab);
     SZ_HIP(hipGetLastError());
     return SZH_OK;
 }
@@ -709,8 +927,26 @@ int net_accumulate(Net* n, const AccumArgs& a, hipStream_t s)
                            P + n->off_w2(), (int)n->h1, (int)n->h2, w.w2t);
     }
     SZ_HIP(hipGetLastError());
+    // Every chunk adds its split-K partials into the same slabs (the first one overwrites them);
+    // the slabs are folded into the gradient vector once, after the last chunk.
+    const uint64_t rows0 = std::min<uint64_t>(kChunkRows, a.rows);
+    const SplitPlan sp = plan_splits(rows0);
+    const bool mfma_head = n->out <= 16 && (n->h2 == 64 || n->h2 == 128 || n->h2 == 256);
+    const bool use_head = mfma_head || (n->out <= 32 && n->h2 <= 256 && (n->h2 % 4) == 0);
+    const uint64_t len3 = (uint64_t)n->h2 * n->out + n->out;
+    int head_blocks = 0, head_tpb = 1;
+    if (mfma_head) {
+        const uint64_t wave_tiles = (rows0 + 15) / 16;
+        head_blocks = (int)std::min<uint64_t>(kMHeadBlocks, (wave_tiles + 3) / 4);
+    } else if (use_head) {
+        const int tiles = (int)((rows0 + kHeadRows - 1) / kHeadRows);
+        head_blocks = tiles < 2048 ? tiles : 2048;
+        head_tpb = (tiles + head_blocks - 1) / head_blocks;
+        head_blocks = (tiles + head_tpb - 1) / head_tpb;
+    }
     for (uint64_t r0 = 0; r0 < a.rows; r0 += kChunkRows) {
         const uint64_t R = std::min<uint64_t>(kChunkRows, a.rows - r0);
+        const bool add = r0 != 0;
         // gather / dropout / live flags
         {
             ProfScope prof("prep", s);
@@ -722,45 +958,39 @@ int net_accumulate(Net* n, const AccumArgs& a, hipStream_t s)
         SZ_HIP(hipGetLastError());
         rc = forward_hidden(n, w.xd, R, false, s);
         if (rc) return rc;
-        const bool use_head = n->out <= 32 && n->h2 <= 256 && (n->h2 % 4) == 0;
         if (use_head) {
             HeadArgs h{};
             h.h2 = w.h2; h.w3 = P + n->off_w3(); h.b3 = P + n->off_b3();
             h.target = a.target_dev; h.labels = a.labels_dev ? a.labels_dev + r0 : nullptr; h.live = w.live;
             h.d2 = w.d2; h.stats = n->d_stats; h.rows = R; h.H2 = (int)n->h2; h.C = (int)n->out;
             h.Cp = n->out <= 4 ? 4 : (n->out <= 8 ? 8 : (n->out <= 16 ? 16 : 32));
-            const int tiles = (int)((R + kHeadRows - 1) / kHeadRows);
-            int blocks = tiles < 2048 ? tiles : 2048;
-            h.tiles_per_block = (tiles + blocks - 1) / blocks;
-            blocks = (tiles + h.tiles_per_block - 1) / h.tiles_per_block;
-            const uint64_t len3 = (uint64_t)n->h2 * n->out + n->out;
-            h.slab_w3 = w.slab;
-            h.slab_b2 = w.slab + (size_t)blocks * len3;
-            const int ldh = (int)n->h2 + 4;
-            const size_t lds = sizeof(float) * ((size_t)kHeadRows * ldh + (size_t)n->h2 * h.Cp + (size_t)h.Cp * ldh +
-                                                (size_t)kHeadRows * h.Cp);
-            static bool attr_set = false;
-            if (!attr_set) {
-                const void* fns[] = {(const void*)head_kernel<4>, (const void*)head_kernel<8>,
-                                     (const void*)head_kernel<16>, (const void*)head_kernel<32>};
-                for (const void* fn : fns)
-                    SZ_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024));
-                attr_set = true;
-            }
-            {
-                ProfScope prof("head", s);
-                if (h.Cp <= 4) { h.Cp = 4; hipLaunchKernelGGL(head_kernel<4>, dim3(blocks), dim3(kHeadThreads), lds, s, h); }
-                else if (h.Cp <= 8) { h.Cp = 8; hipLaunchKernelGGL(head_kernel<8>, dim3(blocks), dim3(kHeadThreads), lds, s, h); }
-                else if (h.Cp <= 16) { h.Cp = 16; hipLaunchKernelGGL(head_kernel<16>, dim3(blocks), dim3(kHeadThreads), lds, s, h); }
-                else { h.Cp = 32; hipLaunchKernelGGL(head_kernel<32>, dim3(blocks), dim3(kHeadThreads), lds, s, h); }
-            }
-            SZ_HIP(hipGetLastError());
-            {
-                ProfScope prof("reduce", s);
-                hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((len3 + 31) / 32)), dim3(256), 0, s,
-                                   (const float*)h.slab_w3, blocks, len3, G + n->off_w3());
-                hipLaunchKernelGGL(slab_reduce_kernel, dim3((n->h2 + 31) / 32), dim3(256), 0, s,
-                                   (const float*)h.slab_b2, blocks, (uint64_t)n->h2, G + n->off_b2());
+            h.tiles_per_block = head_tpb;
+            h.add = add ? 1 : 0;
+            h.slab_w3 = w.slab + w.sl_w3;
+            h.slab_b2 = w.slab + w.sl_b2;
+            ProfScope prof("head", s);
+            if (mfma_head) {
+                // the grid is the same for every chunk, so that each workgroup keeps its slab
+                if (n->h2 == 256) hipLaunchKernelGGL(head_mfma_kernel<16>, dim3(head_blocks), dim3(256), 0, s, h);
+                else if (n->h2 == 128) hipLaunchKernelGGL(head_mfma_kernel<8>, dim3(head_blocks), dim3(256), 0, s, h);
+                else hipLaunchKernelGGL(head_mfma_kernel<4>, dim3(head_blocks), dim3(256), 0, s, h);
+            } else {
+                const int blocks = (int)(((R + kHeadRows - 1) / kHeadRows + head_tpb - 1) / head_tpb);
+                const int ldh = (int)n->h2 + 4;
+                const size_t lds = sizeof(float) * ((size_t)kHeadRows * ldh + (size_t)n->h2 * h.Cp +
+                                                    (size_t)h.Cp * ldh + (size_t)kHeadRows * h.Cp);
+                static bool attr_set = false;
+                if (!attr_set) {
+                    const void* fns[] = {(const void*)head_kernel<4>, (const void*)head_kernel<8>,
+                                         (const void*)head_kernel<16>, (const void*)head_kernel<32>};
+                    for (const void* fn : fns)
+                        SZ_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024));
+                    attr_set = true;
+                }
+                if (h.Cp == 4) hipLaunchKernelGGL(head_kernel<4>, dim3(blocks), dim3(kHeadThreads), lds, s, h);
+                else if (h.Cp == 8) hipLaunchKernelGGL(head_kernel<8>, dim3(blocks), dim3(kHeadThreads), lds, s, h);
+                else if (h.Cp == 16) hipLaunchKernelGGL(head_kernel<16>, dim3(blocks), dim3(kHeadThreads), lds, s, h);
+                else hipLaunchKernelGGL(head_kernel<32>, dim3(blocks), dim3(kHeadThreads), lds, s, h);
             }
             SZ_HIP(hipGetLastError());
         } else {
@@ -779,9 +1009,9 @@ int net_accumulate(Net* n, const AccumArgs& a, hipStream_t s)
             g.M = (int)R; g.N = n->h2; g.K = n->out; g.k_chunk = n->out; g.aux = w.h2; g.ldaux = n->h2;
             rc = launch_gemm<A_ROWS, B_ROWS, EPI_MUL_DTANH, T_DELTA2>(g, 1, s);
             if (rc) return rc;
-            rc = grad_gemm<T_DW3>(n, w.h2, n->h2, w.p, n->out, n->h2, n->out, R, G + n->off_w3(), true, s);
+            rc = grad_gemm<T_DW3>(w.h2, n->h2, w.p, n->out, n->h2, n->out, R, w.slab + w.sl_w3, sp, add, true, s);
             if (rc) return rc;
-            rc = grad_bias(n, w.d2, n->h2, R, G + n->off_b2(), s);
+            rc = colsum_slabs(w.d2, n->h2, R, w.slab + w.sl_b2, sp, add, s);
             if (rc) return rc;
         }
         // delta1 = (delta2 . w2^T) * [h1 > 0]
@@ -791,11 +1021,20 @@ int net_accumulate(Net* n, const AccumArgs& a, hipStream_t s)
         rc = launch_gemm<A_ROWS, B_KROWS, EPI_MUL_DRELU, T_DELTA1>(g, 1, s);
         if (rc) return rc;
         // weight gradients: contractions over the rows ([w1|b1] in one launch via the ones row)
-        rc = grad_gemm<T_DW2>(n, w.h1, n->h1, w.d2, n->h2, n->h1, n->h2, R, G + n->off_w2(), false, s);
+        rc = grad_gemm<T_DW2>(w.h1, n->h1, w.d2, n->h2, n->h1, n->h2, R, w.slab + w.sl_w2, sp, add, false, s);
         if (rc) return rc;
-        rc = grad_gemm<T_DW1>(n, w.xd, n->in, w.d1, n->h1, n->in, n->h1, R, G + n->off_w1(), true, s);
+        rc = grad_gemm<T_DW1>(w.xd, n->in, w.d1, n->h1, n->in, n->h1, R, w.slab + w.sl_w1, sp, add, true, s);
         if (rc) return rc;
     }
+    const int tail_slabs = use_head ? head_blocks : sp.splits;
+    rc = reduce_slabs(w.slab + w.sl_w3, tail_slabs, len3, G + n->off_w3(), s);
+    if (rc) return rc;
+    rc = reduce_slabs(w.slab + w.sl_b2, tail_slabs, n->h2, G + n->off_b2(), s);
+    if (rc) return rc;
+    rc = reduce_slabs(w.slab + w.sl_w2, sp.splits, (uint64_t)n->h1 * n->h2, G + n->off_w2(), s);
+    if (rc) return rc;
+    rc = reduce_slabs(w.slab + w.sl_w1, sp.splits, (uint64_t)(n->in + 1) * n->h1, G + n->off_w1(), s);
+    if (rc) return rc;
     hipLaunchKernelGGL(stats_to_tail_kernel, dim3(1), dim3(64), 0, s, n->d_stats, G + n->param_count());
     SZ_HIP(hipGetLastError());
     return SZH_OK;
