@@ -171,6 +171,7 @@ constexpr int kHeadThreads = 256;
 struct HeadArgs {
     const float* h2;       // [rows][H2]
     const float* w3;       // [H2][C]
+    const float* w3tab;    // head_mfma_kernel only: output of head_tables_kernel
     const float* b3;       // [C]
     const float* target;   // [C] shared target, or
     const int32_t* labels; // [rows]
@@ -178,7 +179,7 @@ struct HeadArgs {
     float* d2;             // [rows][H2] out
     float* slab_w3;        // [blocks][H2*C + C]  (dW3 then db3, the layout of the gradient vector)
     float* slab_b2;        // [blocks][H2]
-    double* stats;
+    double* stats;         // [blocks][2] loss and live-row partials
     uint64_t rows;
     int H2, C, Cp;         // Cp = C rounded up to a multiple of 4
     int tiles_per_block;
@@ -357,10 +358,11 @@ __global__ __launch_bounds__(kHeadThreads) void head_kernel(HeadArgs a)
     if (tid == 0) {
         const double ls = (s_stat[0] + s_stat[1]) + (s_stat[2] + s_stat[3]);
         const double lv = (s_stat[4] + s_stat[5]) + (s_stat[6] + s_stat[7]);
-        if (lv > 0.0) {
-            atomicAdd(&a.stats[0], ls);
-            atomicAdd(&a.stats[1], lv);
-        }
+        // per-workgroup partials (thousands of same-address atomics at the end of the kernel
+        // would queue up at one L2 channel)
+        double* st = a.stats + 2 * (size_t)blockIdx.x;
+        st[0] = (a.add ? st[0] : 0.0) + ls;
+        st[1] = (a.add ? st[1] : 0.0) + lv;
     }
 }
 
@@ -381,7 +383,47 @@ __global__ __launch_bounds__(kHeadThreads) void head_kernel(HeadArgs a)
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kMHeadBlocks = 512;
 
+// value of the same register in another lane of the row of 16, by a DPP pattern
+template <int CTRL>
+__device__ __forceinline__ float dpp_read(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+// all-reduce over each row of 16 lanes: lanes ^1, ^2 (quad permutes), then the mirrored half rows
+__device__ __forceinline__ float row16_max(float x)
+{
+    x = fmaxf(x, dpp_read<0xB1>(x));
+    x = fmaxf(x, dpp_read<0x4E>(x));
+    x = fmaxf(x, dpp_read<0x141>(x));
+    return fmaxf(x, dpp_read<0x140>(x));
+}
+__device__ __forceinline__ float row16_sum(float x)
+{
+    x += dpp_read<0xB1>(x);
+    x += dpp_read<0x4E>(x);
+    x += dpp_read<0x141>(x);
+    return x + dpp_read<0x140>(x);
+}
+
 #define SZ_MFMA16(a_, b_, c_) __builtin_amdgcn_mfma_f32_16x16x4f32((a_), (b_), (c_), 0, 0, 0)
+
+// w3 in the two MFMA operand layouts head_mfma_kernel multiplies with, as float4 per lane:
+// tab[j*64 + lane] = w3[16j + 4g + 0..3][m], tab[(KB + j)*64 + lane] = w3[16j + m][4g + 0..3],
+// zero beyond column C.
+__global__ void head_tables_kernel(const float* __restrict__ w3, int KB, int C, float* __restrict__ tab)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= KB * 64) return;
+    const int j = e >> 6, mm = e & 15, gg = (e & 63) >> 4;
+    float t[4], u[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        t[q] = mm < C ? w3[(size_t)(16 * j + 4 * gg + q) * C + mm] : 0.0f;
+        u[q] = 4 * gg + q < C ? w3[(size_t)(16 * j + mm) * C + 4 * gg + q] : 0.0f;
+    }
+    reinterpret_cast<float4*>(tab)[e] = make_float4(t[0], t[1], t[2], t[3]);
+    reinterpret_cast<float4*>(tab)[KB * 64 + e] = make_float4(u[0], u[1], u[2], u[3]);
+}
 
 template <int KB>
 __global__ __launch_bounds__(256, 2) void head_mfma_kernel(HeadArgs a)
@@ -390,20 +432,9 @@ __global__ __launch_bounds__(256, 2) void head_mfma_kernel(HeadArgs a)
     __shared__ __attribute__((aligned(16))) float tab[2 * KB * 64 * 4];
     float4* Wb = reinterpret_cast<float4*>(tab);  // [KB][lane]: w3[16j + 4g + s][m], s = x..w
     float4* Wa = Wb + KB * 64;                    // [KB][lane]: w3[16j + m][4g + i], i = x..w
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, m = lane & 15, g = lane >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, m = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // uniform: tile indices stay in scalar registers
     const int C = a.C;
-    for (int e = tid; e < KB * 64; e += 256) {
-        const int j = e >> 6, mm = e & 15, gg = (e & 63) >> 4;
-        float t[4], u[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            t[q] = mm < C ? a.w3[(size_t)(16 * j + 4 * gg + q) * C + mm] : 0.0f;
-            u[q] = 4 * gg + q < C ? a.w3[(size_t)(16 * j + mm) * C + 4 * gg + q] : 0.0f;
-        }
-        Wb[e] = make_float4(t[0], t[1], t[2], t[3]);
-        Wa[e] = make_float4(u[0], u[1], u[2], u[3]);
-    }
-    __syncthreads();
     const bool cls = m < C;
     const float b3m = cls ? a.b3[m] : 0.0f;
     const float tgt_m = (a.target && cls) ? a.target[m] : 0.0f;
@@ -419,25 +450,60 @@ __global__ __launch_bounds__(256, 2) void head_mfma_kernel(HeadArgs a)
         for (int q = 0; q < 4; ++q) acc3[j][q] = 0.0f;
     }
     float accb3 = 0.0f;
-    double loss_sum = 0.0, live_sum = 0.0;
+    double loss_sum = 0.0;
+    float live_cnt = 0.0f;  // exact: a lane sees far fewer than 2^24 rows
 
+    {   // both operand layouts of w3, prepared by head_tables_kernel
+        const float4* src = reinterpret_cast<const float4*>(a.w3tab);
+        float4* dst = reinterpret_cast<float4*>(tab);
+#pragma unroll
+        for (int e = tid; e < 2 * KB * 64; e += 256) dst[e] = src[e];
+    }
+    // The h2 tile of a wave's next 16 rows is requested while the current one is still being
+    // worked on (each register is refilled right after its last use), so that the memory latency is paid
+    // once per wave.
     const uint64_t tiles = (a.rows + 15) / 16;
-    for (uint64_t t = (uint64_t)blockIdx.x * 4 + wave; t < tiles; t += (uint64_t)gridDim.x * 4) {
+    const uint64_t t_step = (uint64_t)gridDim.x * 4;
+    uint64_t t = (uint64_t)blockIdx.x * 4 + wave;
+    float4 Ha[KB];
+    {
+        // rows past the end read row 0 instead: their delta3 is zero, so any finite value will do
+        const bool ok0 = t < tiles && t * 16 + m < a.rows;
+        const float* h0 = a.h2 + (ok0 ? t * 16 + m : 0) * H2 + 4 * g;
+#pragma unroll
+        for (int j = 0; j < KB; ++j) Ha[j] = *reinterpret_cast<const float4*>(h0 + 16 * j);
+    }
+    // labels and live flags of rows 4g..4g+3 travel with the tile (row indices clamped, so the
+    // loads are unconditional and issue together)
+    uint32_t lab4 = 0xffffffffu;  // one byte per row (C <= 16)
+    uint32_t live4 = 0x01010101u;
+    auto fetch_row_info = [&](uint64_t tile) {
+        const uint64_t last = a.rows - 1;
+        const uint64_t rb = min(tile * 16 + 4 * g, last);
+        if (a.labels) {
+            lab4 = 0;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) lab4 |= ((uint32_t)a.labels[min(rb + v, last)] & 0xffu) << (8 * v);
+        }
+        if (a.live) {
+            live4 = 0;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) live4 |= (uint32_t)a.live[min(rb + v, last)] << (8 * v);
+        }
+    };
+    fetch_row_info(t);
+    __syncthreads();
+    for (; t < tiles; t += t_step) {
         const uint64_t r0 = t * 16, rm = r0 + m;
         const bool okm = rm < a.rows;
-        const float* hrow = a.h2 + rm * H2 + 4 * g;
-        float4 Ha[KB];
-#pragma unroll
-        for (int j = 0; j < KB; ++j)
-            Ha[j] = okm ? *reinterpret_cast<const float4*>(hrow + 16 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const bool okn = t + t_step < tiles && (t + t_step) * 16 + m < a.rows;
+        const float* hnext = a.h2 + (okn ? (t + t_step) * 16 + m : 0) * H2 + 4 * g;
         f32x4 L = {0.f, 0.f, 0.f, 0.f};
         // The scheduling barriers keep the compiler from hoisting every operand read of the
         // unrolled loops to the top, which would need far more registers than there are.
-        float4 wb_next = Wb[lane];
 #pragma unroll
         for (int j = 0; j < KB; ++j) {
-            const float4 wb = wb_next;
-            if (j + 1 < KB) wb_next = Wb[(j + 1) * 64 + lane];
+            const float4 wb = Wb[j * 64 + lane];
             L = SZ_MFMA16(Ha[j].x, wb.x, L);
             L = SZ_MFMA16(Ha[j].y, wb.y, L);
             L = SZ_MFMA16(Ha[j].z, wb.z, L);
@@ -451,39 +517,30 @@ __global__ __launch_bounds__(256, 2) void head_mfma_kernel(HeadArgs a)
             const uint64_t rv = r0 + 4 * g + v;
             const bool okv = rv < a.rows;
             const float x = cls ? L[v] + b3m : -INFINITY;
-            float mx = x;
-            mx = fmaxf(mx, __shfl_xor(mx, 1));
-            mx = fmaxf(mx, __shfl_xor(mx, 2));
-            mx = fmaxf(mx, __shfl_xor(mx, 4));
-            mx = fmaxf(mx, __shfl_xor(mx, 8));
+            const float mx = row16_max(x);
             const float e = cls ? expf(x - mx) : 0.0f;
-            float sum = e;
-            sum += __shfl_xor(sum, 1);
-            sum += __shfl_xor(sum, 2);
-            sum += __shfl_xor(sum, 4);
-            sum += __shfl_xor(sum, 8);
+            const float sum = row16_sum(e);
             const float o = e / sum;
-            const bool alive = okv && (a.live ? a.live[rv] != 0 : true);
-            const int lab = (okv && a.labels) ? a.labels[rv] : -1;
-            const float tj = a.labels ? (m == lab ? 1.0f : 0.0f) : tgt_m;
+            const bool alive = okv && ((live4 >> (8 * v)) & 0xffu) != 0;
+            const float tj = a.labels ? (m == (int)((lab4 >> (8 * v)) & 0xffu) ? 1.0f : 0.0f) : tgt_m;
             float d = 0.0f;
             if (alive && cls) {
                 if (tj != 0.0f) loss_sum -= (double)(tj * logf(fmaxf(o, 1e-12f)));
                 d = o - tj;
             }
-            if (alive && m == 0) live_sum += 1.0;
+            if (alive && m == 0) live_cnt += 1.0f;
             d3[v] = d;
             accb3 += d;
         }
         f32x4 d3t = {0.f, 0.f, 0.f, 0.f};  // delta3[row m][class 4g+v]
 #pragma unroll
         for (int v = 0; v < 4; ++v) d3t = SZ_MFMA16(d3[v], ident[v], d3t);
-        float4 wa_next = Wa[lane];
 #pragma unroll
         for (int j = 0; j < KB; ++j) {
             const float4 h = Ha[j];
-            const float4 wa = wa_next;
-            if (j + 1 < KB) wa_next = Wa[(j + 1) * 64 + lane];
+            // refill the registers whose value died with the previous block
+            if (j > 0) Ha[j - 1] = *reinterpret_cast<const float4*>(hnext + 16 * (j - 1));
+            const float4 wa = Wa[j * 64 + lane];
             f32x4 hb = {0.f, 0.f, 0.f, 0.f};  // h2[row 4g+v][16j + m]
             hb = SZ_MFMA16(h.x, ident[0], hb);
             hb = SZ_MFMA16(h.y, ident[1], hb);
@@ -508,8 +565,25 @@ __global__ __launch_bounds__(256, 2) void head_mfma_kernel(HeadArgs a)
             if (okm) *reinterpret_cast<float4*>(a.d2 + rm * H2 + 16 * j + 4 * g) = o;
             __builtin_amdgcn_sched_barrier(0);
         }
+        Ha[KB - 1] = *reinterpret_cast<const float4*>(hnext + 16 * (KB - 1));
+        fetch_row_info(t + t_step);
     }
 
+    // slab (+)= sums: the slab's current contents are requested now, ahead of the reductions, so
+    // that their latency is hidden
+    const int len3 = H2 * C + C;
+    float* sw = a.slab_w3 + (size_t)blockIdx.x * len3;
+    float* sb = a.slab_b2 + (size_t)blockIdx.x * H2;
+    constexpr int kPer = (H2 * 16 + 16 + 255) / 256;  // len3 <= 16 (H2 + 1)
+    float prev[kPer + 1];
+#pragma unroll
+    for (int q = 0; q < kPer; ++q) {
+        const int i = tid + 256 * q;
+        prev[q] = (a.add && i < len3) ? sw[i] : 0.0f;
+    }
+    prev[kPer] = (a.add && tid < H2) ? sb[tid] : 0.0f;
+    double st_prev[2] = {0.0, 0.0};
+    if (a.add && tid == 0) { st_prev[0] = a.stats[2 * (size_t)blockIdx.x]; st_prev[1] = a.stats[2 * (size_t)blockIdx.x + 1]; }
     // sums over the rows held by different lane groups
 #pragma unroll
     for (int j = 0; j < KB; ++j) {
@@ -518,45 +592,63 @@ __global__ __launch_bounds__(256, 2) void head_mfma_kernel(HeadArgs a)
     }
     accb3 += __shfl_xor(accb3, 16);
     accb3 += __shfl_xor(accb3, 32);
-    __syncthreads();  // every wave is done with the w3 tables; their LDS now holds the sums
-    float* red = tab;                         // [H2*C + C] (dW3 then db3), then [H2] (db2)
-    const int len3 = H2 * C + C;
-    for (int w = 0; w < 4; ++w) {
-        if (wave == w) {
-#pragma unroll
-            for (int j = 0; j < KB; ++j)
-#pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    const int k = 16 * j + 4 * g + v;
-                    if (cls) red[k * C + m] = (w ? red[k * C + m] : 0.0f) + acc3[j][v];
-                }
-            if (g == 0) {
-#pragma unroll
-                for (int j = 0; j < KB; ++j) red[len3 + 16 * j + m] = (w ? red[len3 + 16 * j + m] : 0.0f) + accb2[j];
-                if (cls) red[H2 * C + m] = (w ? red[H2 * C + m] : 0.0f) + accb3;
-            }
-        }
-        __syncthreads();
-    }
-    float* sw = a.slab_w3 + (size_t)blockIdx.x * len3;
-    for (int i = tid; i < len3; i += 256) sw[i] = (a.add ? sw[i] : 0.0f) + red[i];
-    float* sb = a.slab_b2 + (size_t)blockIdx.x * H2;
-    for (int i = tid; i < H2; i += 256) sb[i] = (a.add ? sb[i] : 0.0f) + red[len3 + i];
-
+    double live_sum = (double)live_cnt;
     for (int off = 32; off > 0; off >>= 1) {
         loss_sum += __shfl_down(loss_sum, off);
         live_sum += __shfl_down(live_sum, off);
     }
     __shared__ double s_stat[8];
     if (lane == 0) { s_stat[wave] = loss_sum; s_stat[4 + wave] = live_sum; }
+    __syncthreads();  // every wave is done with the w3 tables; their LDS now holds the sums
+    // Waves 0 and 1 store their dW3 partials lane-major (no bank conflicts) into the two halves
+    // of the table space, waves 2 and 3 add theirs; the sum is ((w0 + w2) + (w1 + w3)).
+    __shared__ float redb[4][H2 + 16];  // per wave: db2[H2], db3[16]
+    float* RW = tab + (wave & 1) * (KB * 256);
+    if (wave < 2) {
+#pragma unroll
+        for (int j = 0; j < KB; ++j)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) RW[(4 * j + v) * 64 + lane] = acc3[j][v];
+    }
+    if (g == 0) {
+#pragma unroll
+        for (int j = 0; j < KB; ++j) redb[wave][16 * j + m] = accb2[j];
+        redb[wave][H2 + m] = accb3;
+    }
     __syncthreads();
+    if (wave >= 2) {
+#pragma unroll
+        for (int j = 0; j < KB; ++j)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) RW[(4 * j + v) * 64 + lane] += acc3[j][v];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < kPer; ++q) {
+        const int i = tid + 256 * q;
+        if (i < len3) {
+            float sum;
+            if (i < H2 * C) {  // dW3[k][c] sits at register (k/16, k%4) of lane 16 ((k%16)/4) + c
+                const int k = i / C, c = i - k * C;
+                const int at = (4 * (k >> 4) + (k & 3)) * 64 + 16 * ((k & 15) >> 2) + c;
+                sum = tab[at] + tab[KB * 256 + at];
+            } else {
+                const int c = i - H2 * C;
+                sum = (redb[0][H2 + c] + redb[2][H2 + c]) + (redb[1][H2 + c] + redb[3][H2 + c]);
+            }
+            sw[i] = prev[q] + sum;
+        }
+    }
+    if (tid < H2) sb[tid] = prev[kPer] + ((redb[0][tid] + redb[2][tid]) + (redb[1][tid] + redb[3][tid]));
+
     if (tid == 0) {
         const double ls = (s_stat[0] + s_stat[1]) + (s_stat[2] + s_stat[3]);
         const double lv = (s_stat[4] + s_stat[5]) + (s_stat[6] + s_stat[7]);
-        if (lv > 0.0) {
-            atomicAdd(&a.stats[0], ls);
-            atomicAdd(&a.stats[1], lv);
-        }
+        // per-workgroup partials (thousands of same-address atomics at the end of the kernel
+        // would queue up at one L2 channel)
+        double* st = a.stats + 2 * (size_t)blockIdx.x;
+        st[0] = st_prev[0] + ls;
+        st[1] = st_prev[1] + lv;
     }
 }
 
@@ -643,11 +735,24 @@ __global__ void stats_fold_kernel(double* __restrict__ stats)
     }
 }
 
-__global__ void stats_to_tail_kernel(const double* __restrict__ stats, float* __restrict__ tail)
+// stats += the per-workgroup {loss, live rows} partials of the head kernels (fixed order), then
+// the totals since the last zero_grad go to the two floats behind the gradient vector
+__global__ __launch_bounds__(256) void stats_finish_kernel(const double* __restrict__ part, int n_part,
+                                                           double* __restrict__ stats, float* __restrict__ tail)
 {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        tail[0] = (float)stats[0];
-        tail[1] = (float)stats[1];
+    __shared__ double sl[256], sc[256];
+    double l = 0.0, c = 0.0;
+    for (int i = threadIdx.x; i < n_part; i += 256) { l += part[2 * i]; c += part[2 * i + 1]; }
+    sl[threadIdx.x] = l; sc[threadIdx.x] = c;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) { sl[threadIdx.x] += sl[threadIdx.x + off]; sc[threadIdx.x] += sc[threadIdx.x + off]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double ls = stats[0] + sl[0], lv = stats[1] + sc[0];
+        stats[0] = ls; stats[1] = lv;
+        tail[0] = (float)ls; tail[1] = (float)lv;
     }
 }
 
@@ -673,6 +778,7 @@ int ensure_workspace(Net* n, uint64_t rows)
     float** ptrs[] = {&w.xd, &w.h1, &w.h2, &w.p, &w.d2, &w.d1, &w.slab, &w.w2t};
     for (float** p : ptrs) { if (*p) (void)hipFree(*p); *p = nullptr; }
     if (w.live) { (void)hipFree(w.live); w.live = nullptr; }
+    if (w.stat_slab) { (void)hipFree(w.stat_slab); w.stat_slab = nullptr; }
     w.rows = 0;
     const uint64_t R = rows < 256 ? 256 : rows;
     // split-K partials live in four regions so that they can accumulate over the chunks of a call
@@ -691,7 +797,8 @@ int ensure_workspace(Net* n, uint64_t rows)
     SZ_HIP(hipMalloc((void**)&w.d1, R * n->h1 * sizeof(float)));
     SZ_HIP(hipMalloc((void**)&w.slab, w.slab_floats * sizeof(float)));
     SZ_HIP(hipMalloc((void**)&w.live, R));
-    SZ_HIP(hipMalloc((void**)&w.w2t, (uint64_t)n->h1 * n->h2 * sizeof(float)));
+    SZ_HIP(hipMalloc((void**)&w.stat_slab, 2 * head_blocks * sizeof(double)));
+    SZ_HIP(hipMalloc((void**)&w.w2t, ((uint64_t)n->h1 * n->h2 + 2 * 64 * 4 * ((n->h2 + 15) / 16)) * sizeof(float)));
     w.rows = R;
     w.out = n->out;
     return SZH_OK;
@@ -814,6 +921,7 @@ void net_destroy(Net* n)
     float* ptrs[] = {w.xd, w.h1, w.h2, w.p, w.d2, w.d1, w.slab, w.w2t, n->d_params, n->d_grad};
     for (float* p : ptrs) if (p) (void)hipFree(p);
     if (w.live) (void)hipFree(w.live);
+    if (w.stat_slab) (void)hipFree(w.stat_slab);
     if (n->d_stats) (void)hipFree(n->d_stats);
     delete n;
 }
@@ -927,6 +1035,7 @@ int net_accumulate(Net* n, const AccumArgs& a, hipStream_t s)
                            P + n->off_w2(), (int)n->h1, (int)n->h2, w.w2t);
     }
     SZ_HIP(hipGetLastError());
+    float* w3tab = w.w2t + (uint64_t)n->h1 * n->h2;  // behind the transposed w2 (a multiple of 4 floats in)
     // Every chunk adds its split-K partials into the same slabs (the first one overwrites them);
     // the slabs are folded into the gradient vector once, after the last chunk.
     const uint64_t rows0 = std::min<uint64_t>(kChunkRows, a.rows);
@@ -936,6 +1045,10 @@ int net_accumulate(Net* n, const AccumArgs& a, hipStream_t s)
     const uint64_t len3 = (uint64_t)n->h2 * n->out + n->out;
     int head_blocks = 0, head_tpb = 1;
     if (mfma_head) {
+        const int kb = (int)n->h2 / 16;
+        hipLaunchKernelGGL(head_tables_kernel, dim3((kb * 64 + 255) / 256), dim3(256), 0, s, P + n->off_w3(), kb,
+                           (int)n->out, w3tab);
+        SZ_HIP(hipGetLastError());
         const uint64_t wave_tiles = (rows0 + 15) / 16;
         head_blocks = (int)std::min<uint64_t>(kMHeadBlocks, (wave_tiles + 3) / 4);
     } else if (use_head) {
@@ -962,7 +1075,7 @@ int net_accumulate(Net* n, const AccumArgs& a, hipStream_t s)
             HeadArgs h{};
             h.h2 = w.h2; h.w3 = P + n->off_w3(); h.b3 = P + n->off_b3();
             h.target = a.target_dev; h.labels = a.labels_dev ? a.labels_dev + r0 : nullptr; h.live = w.live;
-            h.d2 = w.d2; h.stats = n->d_stats; h.rows = R; h.H2 = (int)n->h2; h.C = (int)n->out;
+            h.w3tab = w3tab; h.d2 = w.d2; h.stats = w.stat_slab; h.rows = R; h.H2 = (int)n->h2; h.C = (int)n->out;
             h.Cp = n->out <= 4 ? 4 : (n->out <= 8 ? 8 : (n->out <= 16 ? 16 : 32));
             h.tiles_per_block = head_tpb;
             h.add = add ? 1 : 0;
@@ -1035,7 +1148,8 @@ int net_accumulate(Net* n, const AccumArgs& a, hipStream_t s)
     if (rc) return rc;
     rc = reduce_slabs(w.slab + w.sl_w1, sp.splits, (uint64_t)(n->in + 1) * n->h1, G + n->off_w1(), s);
     if (rc) return rc;
-    hipLaunchKernelGGL(stats_to_tail_kernel, dim3(1), dim3(64), 0, s, n->d_stats, G + n->param_count());
+    hipLaunchKernelGGL(stats_finish_kernel, dim3(1), dim3(256), 0, s, (const double*)w.stat_slab, use_head ? head_blocks : 0,
+                       n->d_stats, G + n->param_count());
     SZ_HIP(hipGetLastError());
     return SZH_OK;
 }
