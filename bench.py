@@ -198,7 +198,6 @@ def main():
 
     # ---- roofline of the dominant kernel, from the event pairs recorded during the timed steps
     C, H1, H2 = args.speakers, args.hidden1, args.hidden2
-    rows_per_launch = 32768  # rows of one launch (the library's chunk); the last chunk is shorter
     flops_per_row = {"fwd1": 2 * 60 * H1, "fwd2": 2 * H1 * H2, "fwd3": 2 * H2 * C, "delta2": 2 * C * H2,
                      "delta1": 2 * H2 * H1, "dw3": 2 * H2 * C, "dw2": 2 * H1 * H2, "dw1": 2 * 60 * H1}
     roofline = None
@@ -215,7 +214,8 @@ def main():
             roofline = {"kernel": dom, "bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MATRIX_TFLOPS,
                         "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MATRIX_TFLOPS, "traffic": None,
                         "avg_launch_us": 1000.0 * ms / cnt,
-                        "flops_per_launch": flops_per_row[dom] * min(rows_per_launch, n_win)}
+                        "launches": cnt, "flops_per_launch": total_flops / cnt,
+                        "rows_per_launch": n_win * args.steps / cnt}
         else:
             total_bytes = 1040.0 * n_win * args.steps
             achieved = total_bytes / (ms * 1e-3) / 1e9

@@ -28,7 +28,9 @@ enum Epi {
     EPI_BIAS = 2,       // C = acc + bias[n]
     EPI_MUL_DTANH = 3,  // C = acc * (1 - aux^2)          (lib.rs:1034)
     EPI_MUL_DRELU = 4,  // C = acc * (aux > 0)            (lib.rs:1039-1040)
-    EPI_SLAB = 5        // C[z] (+)= acc                  (split-K partial)
+    EPI_SLAB = 5,       // C[z] (+)= acc                  (split-K partial)
+    EPI_BIAS_RELU_MASK = 6,  // EPI_BIAS_RELU, and bit (n % 32) of mask[m][n / 32] = (C > 0)
+    EPI_MUL_MASK = 7    // C = acc * bit of mask[m][n / 32]   (same product as EPI_MUL_DRELU)
 };
 
 struct GemmArgs {
@@ -44,9 +46,17 @@ struct GemmArgs {
     int a_vec, b_vec;
     int ones_row = -1;  // A_KROWS only: logical row M-1 of A is all ones (bias-gradient row)
     int slab_add = 0;   // EPI_SLAB only: add to the slab instead of overwriting it
+    uint32_t* mask = nullptr;  // EPI_*_MASK: [M][N / 32] sign bits of the ReLU layer (N % 32 == 0)
 };
 
 struct Frag4 { float v[4]; };
+
+// tanh from the hardware exponential; absolute error ~1e-7
+__device__ __forceinline__ float fast_tanh(float x)
+{
+    const float t = __expf(2.0f * fminf(fmaxf(x, -15.0f), 15.0f));
+    return 1.0f - __fdividef(2.0f, t + 1.0f);
+}
 
 __device__ __forceinline__ Frag4 load4(const float* base, int64_t row, int col, int ld, int row_max, int col_max,
                                        int vec)
@@ -139,7 +149,7 @@ __device__ __forceinline__ void fetch_krows_fast(const float* base, int ld, int 
 
 // TAG only separates instantiations, so that each call site is its own kernel in a profile.
 // TM = rows of the block tile, KT = K tile (16 or 32), DB = double-buffered LDS tiles.
-template <int AM, int BMd, int EPI, int TAG, int TM, int KT, int DB>
+template <int AM, int BMd, int EPI, int TAG, int TM, int KT, int DB, int DBG = 0>
 __global__ __launch_bounds__(kGemmThreads) void gemm_kernel(GemmArgs g)
 {
     constexpr int BK = KT;
@@ -214,25 +224,27 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_kernel(GemmArgs g)
     if (DB && k_begin < k_end) { stash(0); __syncthreads(); }
     int buf = 0;
     for (int k0 = k_begin; k0 < k_end; k0 += BK) {
-        if (!DB) {
+        if (!DB && (!(DBG & 1) || k0 == k_begin)) {
             __syncthreads();
             stash(0);
             __syncthreads();
         }
-        if (k0 + BK < k_end) fetch(k0 + BK);
+        if (!(DBG & 1) && k0 + BK < k_end) fetch(k0 + BK);
         const float* As = As_ + buf * BK * LDT;
         const float* Bs = Bs_ + buf * BK * LDT;
         // fragments of k-step kk+2 are read from LDS while the MFMAs of k-step kk run
         const float* ar = As + half * LDA + wm * 64 + l31;
         const float* br = Bs + half * LDB + wn * WN + l31;
         float fa0[2], fa1[2], fbn[2][TN];
+        if (!((DBG & 2) && k0 != k_begin)) {
         fa0[0] = ar[0]; fa1[0] = ar[32];
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) fbn[0][tn] = br[32 * tn];
+        }
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
             const int cur = (kk >> 1) & 1, nxt = cur ^ 1;
-            if (kk + 2 < BK) {
+            if (kk + 2 < BK && !((DBG & 2) && k0 != k_begin)) {
                 fa0[nxt] = ar[(kk + 2) * LDA]; fa1[nxt] = ar[(kk + 2) * LDA + 32];
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn) fbn[nxt][tn] = br[(kk + 2) * LDB + 32 * tn];
@@ -257,17 +269,28 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_kernel(GemmArgs g)
             const int col = n0 + wn * WN + tn * 32 + l31;
             if (col >= g.N) continue;
             float bias = 0.0f;
-            if (EPI == EPI_BIAS_RELU || EPI == EPI_BIAS_TANH || EPI == EPI_BIAS) bias = g.bias[col];
+            if (EPI == EPI_BIAS_RELU || EPI == EPI_BIAS_TANH || EPI == EPI_BIAS || EPI == EPI_BIAS_RELU_MASK)
+                bias = g.bias[col];
+            const int mask_ld = g.N >> 5;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (row >= g.M) continue;
                 float v = acc[tm][tn][r];
+                if (EPI == EPI_BIAS_RELU_MASK) {
+                    // whole wave takes part: lanes 0-31 hold 32 columns of `row`, lanes 32-63 of row + 4
+                    v += bias;
+                    const unsigned long long pos = __ballot(v > 0.0f);
+                    if (l31 == 0 && row < g.M)
+                        g.mask[(size_t)row * mask_ld + (col >> 5)] = (uint32_t)(half ? pos >> 32 : pos);
+                    v = v > 0.0f ? v : 0.0f;
+                }
+                if (row >= g.M) continue;
                 if (EPI == EPI_BIAS_RELU) { v += bias; v = v > 0.0f ? v : 0.0f; }
-                else if (EPI == EPI_BIAS_TANH) v = tanhf(v + bias);
+                else if (EPI == EPI_BIAS_TANH) v = fast_tanh(v + bias);
                 else if (EPI == EPI_BIAS) v += bias;
                 else if (EPI == EPI_MUL_DTANH) { const float h = g.aux[(size_t)row * g.ldaux + col]; v *= (1.0f - h * h); }
                 else if (EPI == EPI_MUL_DRELU) { const float h = g.aux[(size_t)row * g.ldaux + col]; v *= (h > 0.0f ? 1.0f : 0.0f); }
+                else if (EPI == EPI_MUL_MASK) { if (!((g.mask[(size_t)row * mask_ld + (col >> 5)] >> l31) & 1u)) v = 0.0f; }
                 C[(size_t)row * g.ldc + col] = v;
             }
         }

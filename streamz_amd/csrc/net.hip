@@ -7,6 +7,7 @@
 // activation / derivative is fused into the epilogue.  Weight gradients are contractions over
 // the batch: they are split over the batch dimension into slabs and summed by a second
 // kernel, so the result does not depend on scheduling order.
+#include <cstdlib>
 #include <mutex>
 #include <new>
 
@@ -64,26 +65,34 @@ __host__ __device__ inline float uniform01(uint64_t seed, uint64_t a, uint64_t b
 
 // ---- row preparation: gather by permutation, input dropout, all-zero flag -------------
 // (lib.rs:604-609: clone, apply_dropout, skip rows whose 60 values are all exactly 0.0)
-__global__ void prep_rows_kernel(const float* __restrict__ x, const uint32_t* __restrict__ perm,
-                                 const uint8_t* __restrict__ keep, float dropout, uint64_t seed, uint64_t counter0,
-                                 uint64_t rows, int in, int skip_zero, float* __restrict__ xd, uint8_t* __restrict__ live)
+// One workgroup prepares 64 rows, one element per thread and step, so that reads and writes are
+// contiguous; the per-row "any nonzero" flags are gathered in LDS.
+constexpr int kPrepRows = 64;
+__global__ __launch_bounds__(256) void prep_rows_kernel(const float* __restrict__ x, const uint32_t* __restrict__ perm,
+                                                        const uint8_t* __restrict__ keep, float dropout, uint64_t seed,
+                                                        uint64_t counter0, uint64_t rows, int in, int skip_zero,
+                                                        float* __restrict__ xd, uint8_t* __restrict__ live)
 {
-    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= rows) return;
-    const uint64_t src = perm ? perm[r] : r;
-    const float* xi = x + src * in;
-    float* xo = xd + r * in;
-    bool nz = false;
-    for (int j = 0; j < in; ++j) {
-        float v = xi[j];
+    __shared__ unsigned int nz[kPrepRows];
+    const uint64_t r0 = (uint64_t)blockIdx.x * kPrepRows;
+    const int nr = (int)min((uint64_t)kPrepRows, rows - r0);
+    if (threadIdx.x < kPrepRows) nz[threadIdx.x] = 0;
+    __syncthreads();
+    const int n = nr * in;
+    for (int e = threadIdx.x; e < n; e += 256) {
+        const int rl = e / in, j = e - rl * in;
+        const uint64_t r = r0 + rl;
+        const uint64_t src = perm ? perm[r] : r;
+        float v = x[src * in + j];
         bool drop = false;
         if (keep) drop = keep[r * in + j] == 0;
         else if (dropout > 0.0f) drop = uniform01(seed, counter0 + r, (uint64_t)j) < dropout;
         if (drop) v = 0.0f;
-        nz = nz || (v != 0.0f);
-        xo[j] = v;
+        if (v != 0.0f) nz[rl] = 1;  // benign race: every writer stores the same value
+        xd[r0 * in + e] = v;
     }
-    live[r] = (nz || !skip_zero) ? 1 : 0;
+    __syncthreads();
+    if ((int)threadIdx.x < nr) live[r0 + threadIdx.x] = (nz[threadIdx.x] || !skip_zero) ? 1 : 0;
 }
 
 // ---- softmax, loss, output delta -----------------------------------------------------
@@ -767,7 +776,12 @@ __global__ void apply_kernel(float* __restrict__ params, const float* __restrict
 }
 
 // 49 152 rows = 768 block tiles of the large GEMMs = 3 per CU, all resident at once
-constexpr uint64_t kChunkRows = 49152;
+static const uint64_t kChunkRows = [] {
+    // STREAMZ_CHUNK_ROWS overrides the rows per launch (a tuning knob; at least 256, multiple of 128)
+    const char* e = std::getenv("STREAMZ_CHUNK_ROWS");
+    const uint64_t v = e ? std::strtoull(e, nullptr, 10) : 0;
+    return v >= 256 ? (v + 127) / 128 * 128 : (uint64_t)49152;
+}();
 constexpr uint64_t kMaxSplits = 64;  // split-K slabs of a weight-gradient product
 
 int ensure_workspace(Net* n, uint64_t rows)
@@ -778,6 +792,7 @@ int ensure_workspace(Net* n, uint64_t rows)
     float** ptrs[] = {&w.xd, &w.h1, &w.h2, &w.p, &w.d2, &w.d1, &w.slab, &w.w2t};
     for (float** p : ptrs) { if (*p) (void)hipFree(*p); *p = nullptr; }
     if (w.live) { (void)hipFree(w.live); w.live = nullptr; }
+    if (w.mask) { (void)hipFree(w.mask); w.mask = nullptr; }
     if (w.stat_slab) { (void)hipFree(w.stat_slab); w.stat_slab = nullptr; }
     w.rows = 0;
     const uint64_t R = rows < 256 ? 256 : rows;
@@ -797,6 +812,7 @@ int ensure_workspace(Net* n, uint64_t rows)
     SZ_HIP(hipMalloc((void**)&w.d1, R * n->h1 * sizeof(float)));
     SZ_HIP(hipMalloc((void**)&w.slab, w.slab_floats * sizeof(float)));
     SZ_HIP(hipMalloc((void**)&w.live, R));
+    SZ_HIP(hipMalloc((void**)&w.mask, R * ((n->h1 + 31) / 32) * sizeof(uint32_t)));
     SZ_HIP(hipMalloc((void**)&w.stat_slab, 2 * head_blocks * sizeof(double)));
     SZ_HIP(hipMalloc((void**)&w.w2t, ((uint64_t)n->h1 * n->h2 + 2 * 64 * 4 * ((n->h2 + 15) / 16)) * sizeof(float)));
     w.rows = R;
@@ -805,14 +821,16 @@ int ensure_workspace(Net* n, uint64_t rows)
 }
 
 // hidden layers of `rows` rows (rows <= workspace capacity): h1, h2 in the workspace
-int forward_hidden(Net* n, const float* x, uint64_t rows, bool relu2, hipStream_t s)
+int forward_hidden(Net* n, const float* x, uint64_t rows, bool relu2, hipStream_t s, uint32_t* relu_mask = nullptr)
 {
     Workspace& w = n->ws;
     const float* P = n->d_params;
     GemmArgs g{};
     g.A = x; g.lda = n->in; g.B = P + n->off_w1(); g.ldb = n->h1; g.C = w.h1; g.ldc = n->h1;
     g.M = (int)rows; g.N = n->h1; g.K = n->in; g.k_chunk = n->in; g.bias = P + n->off_b1();
-    int rc = launch_gemm<A_ROWS, B_KROWS, EPI_BIAS_RELU, T_FWD1>(g, 1, s);
+    g.mask = relu_mask;
+    int rc = relu_mask ? launch_gemm<A_ROWS, B_KROWS, EPI_BIAS_RELU_MASK, T_FWD1>(g, 1, s)
+                       : launch_gemm<A_ROWS, B_KROWS, EPI_BIAS_RELU, T_FWD1>(g, 1, s);
     if (rc) return rc;
     g = GemmArgs{};
     g.A = w.h1; g.lda = n->h1; g.B = P + n->off_w2(); g.ldb = n->h2; g.C = w.h2; g.ldc = n->h2;
@@ -921,6 +939,7 @@ void net_destroy(Net* n)
     float* ptrs[] = {w.xd, w.h1, w.h2, w.p, w.d2, w.d1, w.slab, w.w2t, n->d_params, n->d_grad};
     for (float* p : ptrs) if (p) (void)hipFree(p);
     if (w.live) (void)hipFree(w.live);
+    if (w.mask) (void)hipFree(w.mask);
     if (w.stat_slab) (void)hipFree(w.stat_slab);
     if (n->d_stats) (void)hipFree(n->d_stats);
     delete n;
@@ -1063,13 +1082,15 @@ int net_accumulate(Net* n, const AccumArgs& a, hipStream_t s)
         // gather / dropout / live flags
         {
             ProfScope prof("prep", s);
-            hipLaunchKernelGGL(prep_rows_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s,
+            hipLaunchKernelGGL(prep_rows_kernel, dim3((unsigned)((R + kPrepRows - 1) / kPrepRows)), dim3(256), 0, s,
                            a.perm_dev ? a.x_dev : a.x_dev + r0 * n->in, a.perm_dev ? a.perm_dev + r0 : nullptr,
                            a.keep_dev ? a.keep_dev + r0 * n->in : nullptr, a.dropout, a.seed, a.row_counter0 + r0, R,
                            (int)n->in, a.skip_zero_rows ? 1 : 0, w.xd, w.live);
         }
         SZ_HIP(hipGetLastError());
-        rc = forward_hidden(n, w.xd, R, false, s);
+        // with hidden1 a multiple of 32 the ReLU derivative travels as one bit per unit
+        uint32_t* relu_mask = (n->h1 % 32) == 0 ? w.mask : nullptr;
+        rc = forward_hidden(n, w.xd, R, false, s, relu_mask);
         if (rc) return rc;
         if (use_head) {
             HeadArgs h{};
@@ -1131,7 +1152,9 @@ int net_accumulate(Net* n, const AccumArgs& a, hipStream_t s)
         GemmArgs g{};
         g.A = w.d2; g.lda = n->h2; g.B = w.w2t; g.ldb = n->h1; g.C = w.d1; g.ldc = n->h1;
         g.M = (int)R; g.N = n->h1; g.K = n->h2; g.k_chunk = n->h2; g.aux = w.h1; g.ldaux = n->h1;
-        rc = launch_gemm<A_ROWS, B_KROWS, EPI_MUL_DRELU, T_DELTA1>(g, 1, s);
+        g.mask = relu_mask;
+        rc = relu_mask ? launch_gemm<A_ROWS, B_KROWS, EPI_MUL_MASK, T_DELTA1>(g, 1, s)
+                       : launch_gemm<A_ROWS, B_KROWS, EPI_MUL_DRELU, T_DELTA1>(g, 1, s);
         if (rc) return rc;
         // weight gradients: contractions over the rows ([w1|b1] in one launch via the ones row)
         rc = grad_gemm<T_DW2>(w.h1, n->h1, w.d2, n->h2, n->h1, n->h2, R, w.slab + w.sl_w2, sp, add, false, s);
