@@ -42,7 +42,7 @@ struct GemmArgs {
     const float* bias;
     const float* aux;
     int ldaux;
-    int k_chunk;   // K range handled by one blockIdx.z
+    int k_chunk;   // K range handled by one grid z index
     int a_vec, b_vec;
     int ones_row = -1;  // A_KROWS only: logical row M-1 of A is all ones (bias-gradient row)
     int slab_add = 0;   // EPI_SLAB only: add to the slab instead of overwriting it
@@ -160,8 +160,21 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_kernel(GemmArgs g)
     constexpr int LDB = BMd == B_ROWS ? LDR : LDT;
     __shared__ __attribute__((aligned(16))) float As_[(DB ? 2 : 1) * BK * LDT];
     __shared__ __attribute__((aligned(16))) float Bs_[(DB ? 2 : 1) * BK * LDT];
-    const int m0 = blockIdx.y * TM, n0 = blockIdx.x * BN;
-    const int k_begin = blockIdx.z * g.k_chunk;
+    // Workgroups are handed to the 8 XCDs round-robin in launch order.  Tiles are renumbered so
+    // that each XCD works on one contiguous run of them (column tiles of a row tile, then row
+    // tiles, then K ranges): neighbours that share operand rows then share one L2.
+    int bx, by, bz;
+    {
+        const unsigned nb = gridDim.x * gridDim.y * gridDim.z;
+        const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        const unsigned xcd = lin & 7u, slot = lin >> 3, q = nb >> 3, r = nb & 7u;
+        const unsigned t = xcd < r ? xcd * (q + 1) + slot : r * (q + 1) + (xcd - r) * q + slot;
+        bx = (int)(t % gridDim.x);
+        by = (int)((t / gridDim.x) % gridDim.y);
+        bz = (int)(t / (gridDim.x * gridDim.y));
+    }
+    const int m0 = by * TM, n0 = bx * BN;
+    const int k_begin = bz * g.k_chunk;
     const int k_end = min(g.K, k_begin + g.k_chunk);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
@@ -169,7 +182,7 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_kernel(GemmArgs g)
     const int a_cols = g.ones_row >= 0 ? g.M - 1 : g.M;  // columns of A that exist in memory (A_KROWS)
 
     float* C = g.C;
-    if (EPI == EPI_SLAB) C += (size_t)blockIdx.z * (size_t)g.M * (size_t)g.ldc;
+    if (EPI == EPI_SLAB) C += (size_t)bz * (size_t)g.M * (size_t)g.ldc;
     // Accumulators start at zero, or, for a split-K slab that is being added to, at the slab's
     // current contents: those loads overlap the first operand fetch.
     f32x16 acc[2][TN];
@@ -199,14 +212,16 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_kernel(GemmArgs g)
     const bool b_inside = g.b_vec && n0 + BN <= g.N;
     auto fetch = [&](int k0) {
         const bool k_inside = k0 + BK <= k_end;
-        if (a_inside && k_inside) {
+        if ((DBG & 16) && k0 != k_begin) {
+        } else if (a_inside && k_inside) {
             if (AM == A_ROWS) fetch_rows_fast<TM, BK>(g.A, g.lda, m0, k0, fa);
             else fetch_krows_fast<TM, BK>(g.A, g.lda, m0, k0, fa);
         } else {
             if (AM == A_ROWS) fetch_rows<TM, BK>(g.A, g.lda, m0, g.M, k0, k_end, g.a_vec, fa);
             else fetch_krows<TM, BK>(g.A, g.lda, m0, a_cols, k0, k_end, g.a_vec, g.ones_row, fa);
         }
-        if (b_inside && k_inside) {
+        if ((DBG & 32) && k0 != k_begin) {
+        } else if (b_inside && k_inside) {
             if (BMd == B_ROWS) fetch_rows_fast<BN, BK>(g.B, g.ldb, n0, k0, fb);
             else fetch_krows_fast<BN, BK>(g.B, g.ldb, n0, k0, fb);
         } else {
@@ -225,9 +240,9 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_kernel(GemmArgs g)
     int buf = 0;
     for (int k0 = k_begin; k0 < k_end; k0 += BK) {
         if (!DB && (!(DBG & 1) || k0 == k_begin)) {
-            __syncthreads();
-            stash(0);
-            __syncthreads();
+            if (!(DBG & 4) || k0 == k_begin) __syncthreads();
+            if (!(DBG & 8) || k0 == k_begin) stash(0);
+            if (!(DBG & 4) || k0 == k_begin) __syncthreads();
         }
         if (!(DBG & 1) && k0 + BK < k_end) fetch(k0 + BK);
         const float* As = As_ + buf * BK * LDT;

@@ -46,6 +46,14 @@ void variant(float* X, float* H1, float* H2, float* D2, float* D1, float* W1, fl
         float d2 = run<A_ROWS, B_KROWS, EPI_BIAS_TANH, 128, KT, DB, 2>(g, 1, 20);
         float d3 = run<A_ROWS, B_KROWS, EPI_BIAS_TANH, 128, KT, DB, 3>(g, 1, 20);
         float d4 = run<A_ROWS, B_KROWS, EPI_BIAS, 128, KT, DB, 0>(g, 1, 20);
+        float e4 = run<A_ROWS, B_KROWS, EPI_BIAS, 128, KT, DB, 16>(g, 1, 20);
+        float e5 = run<A_ROWS, B_KROWS, EPI_BIAS, 128, KT, DB, 32>(g, 1, 20);
+        float e6 = run<A_ROWS, B_KROWS, EPI_BIAS, 128, KT, DB, 48>(g, 1, 20);
+        std::printf("  no tanh: no A fetch %.1f | no B fetch %.1f | no A, no B fetch (stash+barriers stay) %.1f\n", e4, e5, e6);
+        float e1 = run<A_ROWS, B_KROWS, EPI_BIAS, 128, KT, DB, 4>(g, 1, 20);
+        float e2 = run<A_ROWS, B_KROWS, EPI_BIAS, 128, KT, DB, 8>(g, 1, 20);
+        float e3 = run<A_ROWS, B_KROWS, EPI_BIAS, 128, KT, DB, 12>(g, 1, 20);
+        std::printf("  no tanh: full %.1f | no barriers %.1f | no stash %.1f | no barriers, no stash (fetch only) %.1f\n", d4, e1, e2, e3);
         float d5 = run<A_ROWS, B_KROWS, EPI_BIAS, 128, KT, DB, 3>(g, 1, 20);
         std::printf("  fwd2 full %.1f | no global/stash %.1f | no LDS reads %.1f | neither %.1f | no tanh %.1f | neither+no tanh %.1f\n", t2, d1, d2, d3, d4, d5);
     }
