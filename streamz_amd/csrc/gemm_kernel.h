@@ -46,6 +46,8 @@ struct GemmArgs {
     int a_vec, b_vec;
     int ones_row = -1;  // A_KROWS only: logical row M-1 of A is all ones (bias-gradient row)
     int slab_add = 0;   // EPI_SLAB only: add to the slab instead of overwriting it
+    int a_pad = 0;      // A's allocation is padded (finite values) up to the tile boundary past M resp. K,
+                        // so edge tiles of A may be fetched without bounds checks
     uint32_t* mask = nullptr;  // EPI_*_MASK: [M][N / 32] sign bits of the ReLU layer (N % 32 == 0)
 };
 
@@ -208,12 +210,12 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_kernel(GemmArgs g)
 
     Frag4 fa[TM * BK / 1024], fb[BN * BK / 1024];
     // interior tiles (the common case) take straight-line 16-byte loads; edge tiles are guarded
-    const bool a_inside = g.a_vec && g.ones_row < 0 && m0 + TM <= g.M;
+    const bool a_inside = g.a_vec && g.ones_row < 0 && (m0 + TM <= g.M || (AM == A_KROWS && g.a_pad));
     const bool b_inside = g.b_vec && n0 + BN <= g.N;
     auto fetch = [&](int k0) {
         const bool k_inside = k0 + BK <= k_end;
         if ((DBG & 16) && k0 != k_begin) {
-        } else if (a_inside && k_inside) {
+        } else if (a_inside && (k_inside || (AM == A_ROWS && g.a_pad))) {
             if (AM == A_ROWS) fetch_rows_fast<TM, BK>(g.A, g.lda, m0, k0, fa);
             else fetch_krows_fast<TM, BK>(g.A, g.lda, m0, k0, fa);
         } else {

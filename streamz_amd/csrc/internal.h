@@ -56,6 +56,7 @@ int plan_run(Plan* p, const int16_t* pcm_dev, float* feats_dev, hipStream_t stre
 // ---- network -------------------------------------------------------------------------
 struct Workspace {
     uint64_t rows = 0;  // capacity in rows
+    int ldx = 0;        // row stride of xd
     uint32_t out = 0;   // output width it was sized for
     float *xd = nullptr, *h1 = nullptr, *h2 = nullptr, *p = nullptr, *d2 = nullptr, *d1 = nullptr, *slab = nullptr,
           *w2t = nullptr;

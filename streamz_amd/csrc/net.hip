@@ -71,7 +71,7 @@ constexpr int kPrepRows = 64;
 __global__ __launch_bounds__(256) void prep_rows_kernel(const float* __restrict__ x, const uint32_t* __restrict__ perm,
                                                         const uint8_t* __restrict__ keep, float dropout, uint64_t seed,
                                                         uint64_t counter0, uint64_t rows, int in, int skip_zero,
-                                                        float* __restrict__ xd, uint8_t* __restrict__ live)
+                                                        float* __restrict__ xd, int ldx, uint8_t* __restrict__ live)
 {
     __shared__ unsigned int nz[kPrepRows];
     const uint64_t r0 = (uint64_t)blockIdx.x * kPrepRows;
@@ -89,7 +89,13 @@ __global__ __launch_bounds__(256) void prep_rows_kernel(const float* __restrict_
         else if (dropout > 0.0f) drop = uniform01(seed, counter0 + r, (uint64_t)j) < dropout;
         if (drop) v = 0.0f;
         if (v != 0.0f) nz[rl] = 1;  // benign race: every writer stores the same value
-        xd[r0 * in + e] = v;
+        xd[r * ldx + j] = v;
+    }
+    // column `in` is 1 (it multiplies the bias gradient row of dW1), the rest of the padding 0
+    const int npad = ldx - in;
+    for (int e = threadIdx.x; e < nr * npad; e += 256) {
+        const int rl = e / npad, j = e - rl * npad;
+        xd[(r0 + rl) * ldx + in + j] = j == 0 ? 1.0f : 0.0f;
     }
     __syncthreads();
     if ((int)threadIdx.x < nr) live[r0 + threadIdx.x] = (nz[threadIdx.x] || !skip_zero) ? 1 : 0;
@@ -785,7 +791,9 @@ static const uint64_t kChunkRows = [] {
     const uint64_t v = e ? std::strtoull(e, nullptr, 10) : 0;
     return v >= 256 ? (v + 127) / 128 * 128 : (uint64_t)393216;
 }();
-constexpr uint64_t kMaxSplits = 64;  // split-K slabs of a weight-gradient product
+// Most split-K slabs of a weight-gradient product: enough that tiles x splits is several
+// workgroups per CU (dW1 has only 4 column tiles, dW2 has 8 tiles)
+constexpr uint64_t kMaxSplits = 64, kMaxSplitsW1 = 256;
 
 int ensure_workspace(Net* n, uint64_t rows)
 {
@@ -803,11 +811,13 @@ int ensure_workspace(Net* n, uint64_t rows)
     const uint64_t head_blocks = 2048;  // upper bound of either head kernel's grid
     const uint64_t len3 = (uint64_t)(n->h2 + 1) * n->out;
     w.sl_w1 = 0;
-    w.sl_w2 = w.sl_w1 + kMaxSplits * (uint64_t)(n->in + 1) * n->h1;
+    w.sl_w2 = w.sl_w1 + kMaxSplitsW1 * (uint64_t)(n->in + 1) * n->h1;
     w.sl_w3 = w.sl_w2 + kMaxSplits * (uint64_t)n->h1 * n->h2;
     w.sl_b2 = w.sl_w3 + std::max<uint64_t>(kMaxSplits, head_blocks) * len3;
     w.slab_floats = w.sl_b2 + std::max<uint64_t>(kMaxSplits, head_blocks) * n->h2;
-    SZ_HIP(hipMalloc((void**)&w.xd, R * n->in * sizeof(float)));
+    // prepared rows are padded to a whole tile of columns: [x | 1 | 0...]
+    w.ldx = n->in + 1 <= 64 ? 64 : (int)((n->in + 1 + 127) / 128 * 128);
+    SZ_HIP(hipMalloc((void**)&w.xd, R * w.ldx * sizeof(float)));
     SZ_HIP(hipMalloc((void**)&w.h1, R * n->h1 * sizeof(float)));
     SZ_HIP(hipMalloc((void**)&w.h2, R * n->h2 * sizeof(float)));
     SZ_HIP(hipMalloc((void**)&w.p, R * (n->out ? n->out : 1) * sizeof(float)));
@@ -824,12 +834,14 @@ int ensure_workspace(Net* n, uint64_t rows)
 }
 
 // hidden layers of `rows` rows (rows <= workspace capacity): h1, h2 in the workspace
-int forward_hidden(Net* n, const float* x, uint64_t rows, bool relu2, hipStream_t s, uint32_t* relu_mask = nullptr)
+int forward_hidden(Net* n, const float* x, uint64_t rows, bool relu2, hipStream_t s, uint32_t* relu_mask = nullptr,
+                   int ldx = 0)
 {
     Workspace& w = n->ws;
     const float* P = n->d_params;
     GemmArgs g{};
-    g.A = x; g.lda = n->in; g.B = P + n->off_w1(); g.ldb = n->h1; g.C = w.h1; g.ldc = n->h1;
+    g.A = x; g.lda = ldx ? ldx : (int)n->in; g.a_pad = ldx ? 1 : 0;
+    g.B = P + n->off_w1(); g.ldb = n->h1; g.C = w.h1; g.ldc = n->h1;
     g.M = (int)rows; g.N = n->h1; g.K = n->in; g.k_chunk = n->in; g.bias = P + n->off_b1();
     g.mask = relu_mask;
     int rc = relu_mask ? launch_gemm<A_ROWS, B_KROWS, EPI_BIAS_RELU_MASK, T_FWD1>(g, 1, s)
@@ -855,10 +867,10 @@ int forward_logits(Net* n, uint64_t rows, float* out, hipStream_t s)
 // How the rows of one net_accumulate call are split into K ranges of the weight-gradient
 // products.  Fixed by the first (largest) chunk, so every chunk adds into the same slabs.
 struct SplitPlan { int k_chunk; int splits; };
-SplitPlan plan_splits(uint64_t rows0)
+SplitPlan plan_splits(uint64_t rows0, int max_splits)
 {
     int splits = (int)((rows0 + 511) / 512);
-    if (splits > (int)kMaxSplits) splits = (int)kMaxSplits;
+    if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
     int k_chunk = (int)((rows0 + splits - 1) / splits);
     k_chunk = (k_chunk + BK - 1) / BK * BK;
@@ -871,13 +883,14 @@ SplitPlan plan_splits(uint64_t rows0)
 // the parameter vector.
 template <int TAG>
 int grad_gemm(const float* A, int lda, const float* B, int ldb, int M, int N, uint64_t rows, float* slab,
-              const SplitPlan& sp, bool add, bool bias_row, hipStream_t s)
+              const SplitPlan& sp, bool add, bool bias_row, hipStream_t s, bool a_padded = false)
 {
     GemmArgs g{};
     g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = slab; g.ldc = N;
     g.M = bias_row ? M + 1 : M; g.N = N; g.K = (int)rows; g.k_chunk = sp.k_chunk;
     g.ones_row = bias_row ? M : -1;
     g.slab_add = add ? 1 : 0;
+    g.a_pad = a_padded ? 1 : 0;
     return launch_gemm<A_KROWS, B_KROWS, EPI_SLAB, TAG>(g, (int)((rows + sp.k_chunk - 1) / sp.k_chunk), s);
 }
 
@@ -1061,7 +1074,8 @@ int net_accumulate(Net* n, const AccumArgs& a, hipStream_t s)
     // Every chunk adds its split-K partials into the same slabs (the first one overwrites them);
     // the slabs are folded into the gradient vector once, after the last chunk.
     const uint64_t rows0 = std::min<uint64_t>(kChunkRows, a.rows);
-    const SplitPlan sp = plan_splits(rows0);
+    const SplitPlan sp = plan_splits(rows0, (int)kMaxSplits);
+    const SplitPlan sp1 = plan_splits(rows0, (int)kMaxSplitsW1);
     const bool mfma_head = n->out <= 16 && (n->h2 == 64 || n->h2 == 128 || n->h2 == 256);
     const bool use_head = mfma_head || (n->out <= 32 && n->h2 <= 256 && (n->h2 % 4) == 0);
     const uint64_t len3 = (uint64_t)n->h2 * n->out + n->out;
@@ -1088,12 +1102,12 @@ int net_accumulate(Net* n, const AccumArgs& a, hipStream_t s)
             hipLaunchKernelGGL(prep_rows_kernel, dim3((unsigned)((R + kPrepRows - 1) / kPrepRows)), dim3(256), 0, s,
                            a.perm_dev ? a.x_dev : a.x_dev + r0 * n->in, a.perm_dev ? a.perm_dev + r0 : nullptr,
                            a.keep_dev ? a.keep_dev + r0 * n->in : nullptr, a.dropout, a.seed, a.row_counter0 + r0, R,
-                           (int)n->in, a.skip_zero_rows ? 1 : 0, w.xd, w.live);
+                           (int)n->in, a.skip_zero_rows ? 1 : 0, w.xd, w.ldx, w.live);
         }
         SZ_HIP(hipGetLastError());
         // with hidden1 a multiple of 32 the ReLU derivative travels as one bit per unit
         uint32_t* relu_mask = (n->h1 % 32) == 0 ? w.mask : nullptr;
-        rc = forward_hidden(n, w.xd, R, false, s, relu_mask);
+        rc = forward_hidden(n, w.xd, R, false, s, relu_mask, w.ldx);
         if (rc) return rc;
         if (use_head) {
             HeadArgs h{};
@@ -1162,7 +1176,7 @@ int net_accumulate(Net* n, const AccumArgs& a, hipStream_t s)
         // weight gradients: contractions over the rows ([w1|b1] in one launch via the ones row)
         rc = grad_gemm<T_DW2>(w.h1, n->h1, w.d2, n->h2, n->h1, n->h2, R, w.slab + w.sl_w2, sp, add, false, s);
         if (rc) return rc;
-        rc = grad_gemm<T_DW1>(w.xd, n->in, w.d1, n->h1, n->in, n->h1, R, w.slab + w.sl_w1, sp, add, true, s);
+        rc = grad_gemm<T_DW1>(w.xd, w.ldx, w.d1, n->h1, n->in + 1, n->h1, R, w.slab + w.sl_w1, sp1, add, false, s, true);
         if (rc) return rc;
     }
     const int tail_slabs = use_head ? head_blocks : sp.splits;
@@ -1172,7 +1186,7 @@ int net_accumulate(Net* n, const AccumArgs& a, hipStream_t s)
     if (rc) return rc;
     rc = reduce_slabs(w.slab + w.sl_w2, sp.splits, (uint64_t)n->h1 * n->h2, G + n->off_w2(), s);
     if (rc) return rc;
-    rc = reduce_slabs(w.slab + w.sl_w1, sp.splits, (uint64_t)(n->in + 1) * n->h1, G + n->off_w1(), s);
+    rc = reduce_slabs(w.slab + w.sl_w1, sp1.splits, (uint64_t)(n->in + 1) * n->h1, G + n->off_w1(), s);
     if (rc) return rc;
     hipLaunchKernelGGL(stats_finish_kernel, dim3(1), dim3(256), 0, s, (const double*)w.stat_slab, use_head ? head_blocks : 0,
                        n->d_stats, G + n->param_count());

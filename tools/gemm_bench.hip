@@ -37,6 +37,12 @@ void variant(float* X, float* H1, float* H2, float* D2, float* D1, float* W1, fl
     g = GemmArgs{}; g.A = X; g.lda = IN; g.B = W1; g.ldb = H1n; g.C = H1; g.ldc = H1n; g.M = R; g.N = H1n; g.K = IN; g.k_chunk = IN; g.bias = bias;
     g.a_vec = vec(g.A, g.lda); g.b_vec = vec(g.B, g.ldb);
     float t1 = run<A_ROWS, B_KROWS, EPI_BIAS_RELU, 128, KT, DB>(g, 1, 20);
+    if (KT == 32 && DB == 0) {
+        float f1 = run<A_ROWS, B_KROWS, EPI_BIAS_RELU, 128, KT, DB, 64>(g, 1, 20);
+        float f2 = run<A_ROWS, B_KROWS, EPI_BIAS_RELU, 128, KT, DB, 1>(g, 1, 20);
+        float f3 = run<A_ROWS, B_KROWS, EPI_BIAS_RELU, 128, KT, DB, 65>(g, 1, 20);
+        std::printf("  fwd1 full %.1f | no stores %.1f | no refetch %.1f | neither %.1f\n", t1, f1, f2, f3);
+    }
     // fwd2
     g = GemmArgs{}; g.A = H1; g.lda = H1n; g.B = W2; g.ldb = H2n; g.C = H2; g.ldc = H2n; g.M = R; g.N = H2n; g.K = H1n; g.k_chunk = H1n; g.bias = bias;
     g.a_vec = vec(g.A, g.lda); g.b_vec = vec(g.B, g.ldb);
