@@ -8,8 +8,11 @@
 //                    main.rs:652), written at exit (main.rs:856)
 //   feature_cache/   written by compute_speaker_embeddings -> load_cached_features
 //
-// Not handled here (outside the accelerated path): MP3 input and cache/*.wav, resampling,
-// --eval, --encode / --decode / --checksum.  The reference processes the second pass under a
+//   --eval           scores target_files.txt against the embeddings saved in model.npz
+//                    (main.rs:522-625); nothing is trained or written
+//
+// Not handled here (outside the accelerated path): MP3 input and cache/*.wav,
+// --encode / --decode / --checksum.  The reference processes the second pass under a
 // rayon par_iter whose iterations serialise on the net's write lock in an unspecified order;
 // here the files are taken in list order, one valid schedule of that loop.
 #include <cmath>
@@ -142,6 +145,69 @@ void print_embedding_quality(const SimpleNeuralNet& net, const FeatureExtractor&
     std::printf("Average mean similarity: %.4f\n", sum / (float)e.size());
 }
 
+// --eval, main.rs:522-625: labels of both lists are renumbered densely in ascending order
+// (build_label_map / normalize_with_map, main.rs:281-304); every target file's mean embedding
+// is compared with the saved speaker embeddings; the best similarity above the threshold wins.
+int run_eval(const std::vector<Entry>& train_files, const std::vector<Entry>& target_files,
+             const std::map<std::string, Features>& feature_map, float conf_threshold)
+{
+    std::printf("Evaluating with threshold = %g\n", conf_threshold);
+    std::set<size_t> labels;
+    for (const Entry& e : train_files) if (e.labelled) labels.insert(e.cls);
+    for (const Entry& e : target_files) labels.insert(e.cls);
+    std::map<size_t, size_t> label_map;
+    for (size_t v : labels) { const size_t id = label_map.size(); label_map[v] = id; }
+    if (!exists(MODEL_PATH)) {
+        std::fprintf(stderr, "Model file %s not found. Please train first.\n", MODEL_PATH);
+        return 0;
+    }
+    std::printf("Loading model from %s\n", MODEL_PATH);
+    SimpleNeuralNet net = [&]() -> SimpleNeuralNet {
+        try { return SimpleNeuralNet::load(MODEL_PATH); }
+        catch (const Error& e) { std::fprintf(stderr, "Failed to load model: %s\n", e.what()); std::exit(0); }
+    }();
+    const std::vector<SimpleNeuralNet::Embedding> saved = net.embeddings();
+    std::printf("Model contains %zu saved embeddings\n", saved.size());
+    std::fprintf(stderr, "Total speaker embeddings available: %zu\n", saved.size());
+    size_t true_positive = 0, false_positive = 0, false_negative = 0, correct = 0;
+    const size_t none = (size_t)-1;
+    for (const Entry& e : target_files) {
+        const size_t true_class = label_map[e.cls];
+        auto it = feature_map.find(e.path);
+        if (it == feature_map.end()) { std::fprintf(stderr, "No features found for %s\n", e.path.c_str()); continue; }
+        std::vector<float> embedding = extract_embedding_from_features(net, it->second);
+        normalize(embedding);
+        float norm = 0.0f;
+        for (float v : embedding) norm += v * v;
+        std::fprintf(stderr, "\nEvaluating file: %s\nTrue class: %zu\nEmbedding norm: %.6f\n", e.path.c_str(), true_class,
+                     std::sqrt(norm));
+        size_t best_id = none;
+        float best_sim = -3.4028235e38f;
+        for (size_t id = 0; id < saved.size(); ++id) {
+            const float sim = cosine_similarity(embedding, saved[id].first);
+            std::fprintf(stderr, "  -> Similarity to speaker %zu: %.6f\n", id, sim);
+            if (sim > conf_threshold && sim > best_sim) { best_sim = sim; best_id = id; }
+        }
+        if (best_id == true_class) { ++correct; ++true_positive; }
+        else if (best_id == none) { ++false_negative; std::fprintf(stderr, "  -> Unclassified\n"); }
+        else {
+            ++false_positive;
+            std::fprintf(stderr, "  -> Misclassified: predicted speaker %zu, true speaker %zu\n", best_id, true_class);
+        }
+    }
+    const float total = (float)std::max<size_t>(target_files.size(), 1);
+    const float accuracy = (float)correct / total;
+    const float precision = (float)true_positive / (float)std::max<size_t>(true_positive + false_positive, 1);
+    const float recall = (float)true_positive / (float)std::max<size_t>(true_positive + false_negative, 1);
+    const float f1 = 2.0f * precision * recall / std::max(precision + recall, 1e-6f);
+    std::printf("\nEvaluation complete:\n");
+    std::printf("  Accuracy:  %.2f%%\n", 100.0f * accuracy);
+    std::printf("  Precision: %.2f%%\n", 100.0f * precision);
+    std::printf("  Recall:    %.2f%%\n", 100.0f * recall);
+    std::printf("  F1-score:  %.2f%%\n", 100.0f * f1);
+    return 0;
+}
+
 }  // namespace
 
 int main(int argc, char** argv)
@@ -154,7 +220,8 @@ int main(int argc, char** argv)
         uint64_t seed = 0x5EEDull;
         if ((idx = find_arg(argc, argv, "--seed")) >= 0 && idx + 1 < argc) seed = std::strtoull(argv[idx + 1], nullptr, 10);
         if ((idx = find_arg(argc, argv, "--device")) >= 0 && idx + 1 < argc) check(szh_init(std::atoi(argv[idx + 1])));
-        for (const char* flag : {"--eval", "--encode", "--decode", "--checksum"})
+        const bool eval_mode = find_arg(argc, argv, "--eval") >= 0;  // main.rs:350
+        for (const char* flag : {"--encode", "--decode", "--checksum"})
             if (find_arg(argc, argv, flag) >= 0) {
                 std::fprintf(stderr, "%s is not part of the accelerated path and is not handled by this binary\n", flag);
                 return 2;
@@ -180,7 +247,6 @@ int main(int argc, char** argv)
                 std::fprintf(stderr, "Missing value for --threshold, using default %g\n", DEFAULT_CONF_THRESHOLD);
             }
         }
-        (void)conf_threshold;  // only the --eval mode of the reference reads it
         if ((idx = find_arg(argc, argv, "--burn-in-limit")) >= 0) {  // main.rs:398-410
             size_t v;
             if (idx + 1 < argc && parse_usize(argv[idx + 1], v)) { have_burn = true; burn_in_limit = v; }
@@ -197,6 +263,11 @@ int main(int argc, char** argv)
         // decode once (main.rs:486-490), then the file-parallel extraction loop (main.rs:500-508)
         std::vector<std::string> path_list;
         for (const Entry& e : train_files) path_list.push_back(e.path);
+        std::vector<Entry> target_files;
+        if (eval_mode) {  // main.rs:477, 487-489; load_target_files keeps labelled lines only (main.rs:91-111)
+            for (const Entry& e : load_train_files(TARGET_FILE_LIST))
+                if (e.labelled) { target_files.push_back(e); path_list.push_back(e.path); }
+        }
         auto audio = batch_resample(path_list);
         std::vector<std::vector<int16_t>> clips;
         for (auto& a : audio) clips.push_back(std::move(a.second));
@@ -210,6 +281,8 @@ int main(int argc, char** argv)
         size_t burn_default = (size_t)std::ceil((float)dataset_size * DEFAULT_BURN_IN_FRAC);
         burn_default = std::min<size_t>(std::max<size_t>(burn_default, 10), 50);
         const size_t burn_in_limit_val = have_burn ? burn_in_limit : burn_default;
+
+        if (eval_mode) return run_eval(train_files, target_files, feature_map, conf_threshold);
 
         size_t num_speakers = count_speakers(train_files);  // main.rs:627-650
         const bool model_exists = exists(MODEL_PATH);

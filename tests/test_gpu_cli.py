@@ -171,6 +171,34 @@ def test_cli_trains_ten_clips_two_speakers(sz, tmp_path):
     r2 = subprocess.run([CLI, "--seed", "11"], cwd=tmp_path, capture_output=True, text=True, timeout=600)
     assert r2.returncode == 0, r2.stderr
     assert "Loaded saved model from model.npz" in r2.stdout and "Initial training loss:" not in r2.stdout
+    # --eval (main.rs:522-625): scores target_files.txt against the saved embeddings, writes nothing
+    before = (tmp_path / "model.npz").read_bytes()
+    lists = [(tmp_path / n).read_text() for n in ("train_files.txt", "target_files.txt")]
+    r3 = subprocess.run([CLI, "--eval", "--threshold", "-1.0"], cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert r3.returncode == 0, r3.stderr
+    assert "Evaluating with threshold = -1" in r3.stdout and "Model contains 2 saved embeddings" in r3.stdout
+    m = {k: float(v) for k, v in re.findall(r"(Accuracy|Precision|Recall|F1-score):\s+([0-9.]+)%", r3.stdout)}
+    assert set(m) == {"Accuracy", "Precision", "Recall", "F1-score"}
+    # with every similarity admitted nothing is unclassified, so precision == accuracy and recall is 100 % or 0/1
+    assert r3.stderr.count("Evaluating file:") == 10 and "Unclassified" not in r3.stderr
+    assert abs(m["Precision"] - m["Accuracy"]) < 1e-6
+    # the same decision recomputed from the saved model: nearest saved embedding by cosine similarity
+    z = np.load(tmp_path / "model.npz")
+    cents = z["speaker_embeddings"]
+    net2 = sz.SimpleNeuralNet.load(str(tmp_path / "model.npz"))  # the second run saved a further-trained model
+    hits = 0
+    for i in range(10):
+        emb = net2.forward_embedding(ext.extract(clips[i])).mean(axis=0)
+        emb = emb / max(np.linalg.norm(emb), 1e-6)
+        sims = [float(emb @ c) / max(float(np.linalg.norm(emb) * np.linalg.norm(c)), 1e-6) for c in cents]
+        hits += int(int(np.argmax(sims)) == labels[i])
+    assert abs(m["Accuracy"] - 100.0 * hits / 10) < 1e-3
+    # an unreachable threshold leaves every file unclassified
+    r4 = subprocess.run([CLI, "--eval", "--threshold", "2.0"], cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert r4.returncode == 0 and r4.stderr.count("Unclassified") == 10
+    assert "Accuracy:  0.00%" in r4.stdout and "Recall:    0.00%" in r4.stdout
+    assert (tmp_path / "model.npz").read_bytes() == before
+    assert [(tmp_path / n).read_text() for n in ("train_files.txt", "target_files.txt")] == lists
 
 
 def test_cli_unlabelled_list_discovers_speakers(sz, tmp_path):
