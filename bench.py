@@ -71,7 +71,7 @@ def cpu_baseline(speakers, hidden, seconds):
     from oracle import pyoracle as po
     threads = min(16, os.cpu_count() or 1)
     os.environ["OMP_NUM_THREADS"] = str(threads)
-    n_clips = 8
+    n_clips = 32
     pcm, off, ln = synth_clips(n_clips, seconds, speakers, "cpu")
     pcm = pcm.numpy()
     ext = po.Extractor()
@@ -84,7 +84,7 @@ def cpu_baseline(speakers, hidden, seconds):
     rng = np.random.default_rng(0)
     net.set_params([rng.uniform(-0.5, 0.5, s).astype(np.float32) if len(s) == 2 else np.zeros(s, np.float32)
                     for s in net.shapes()])
-    n_train = 3000
+    n_train = 30000
     t0 = time.perf_counter()
     net.pretrain_from_features(feats[:n_train], 1, speakers, 1, 0.01, 0.2, 8)
     t_tr = time.perf_counter() - t0
@@ -103,6 +103,50 @@ def cpu_baseline(speakers, hidden, seconds):
     }
 
 
+def measured_traffic(kernel, rows_per_launch):
+    """HBM bytes per launch of `kernel` from the newest committed FETCH_SIZE / WRITE_SIZE passes
+    (profiles/*_pmc_traffic.json: separate rocprofv3 --pmc runs of tools/net_bench on the same
+    kernels and row counts, FETCH_SIZE doubled as gfx950 requires), or None."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+    if not files:
+        return None, None
+    with open(files[-1]) as f:
+        t = json.load(f)
+    k = t.get("kernels", {}).get(kernel)
+    if not k:
+        return None, None
+    return k["hbm_bytes_per_row"] * rows_per_launch, os.path.relpath(files[-1], ROOT)
+
+
+def other_figures(sz, ext, plan, pcm, feats, net_dims, n_win, dev, lr, dropout):
+    """Rates reported beside the headline: inference (extract + per-window vote, the
+    identify_speaker_list path) over the same clips, and the reference's own training schedule
+    (batch 8, one optimiser step per 8 windows, lib.rs:599-622) on one clip's windows."""
+    stream = torch.cuda.current_stream().cuda_stream
+    net = sz.SimpleNeuralNet(*net_dims, seed=7)
+    counts = torch.zeros(net_dims[3], dtype=torch.int64, device=dev)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    for it in range(2):
+        if it == 1:
+            ev[0].record()
+        plan.run(pcm.data_ptr(), feats.data_ptr(), stream)
+        net.vote_dev(feats.data_ptr(), n_win, 0.5, counts.data_ptr(), stream)
+    ev[1].record()
+    torch.cuda.synchronize()
+    t_inf = ev[0].elapsed_time(ev[1]) * 1e-3
+    n_b8 = min(n_win, 6614)
+    host = feats[:n_b8].cpu().numpy()
+    sz.pretrain_from_features(net, host[:64], 1, net_dims[3], 1, lr, dropout, 8, seed=1)  # warm
+    t0 = time.perf_counter()
+    sz.pretrain_from_features(net, host, 1, net_dims[3], 1, lr, dropout, 8, seed=2)
+    t_b8 = time.perf_counter() - t0
+    return {"infer_windows_per_s": n_win / t_inf,
+            "infer_note": "extract + forward + thresholded vote (lib.rs:1383-1411) over all clips, device-resident",
+            "cli_batch8_train_windows_per_s": n_b8 / t_b8,
+            "cli_batch8_note": f"pretrain_from_features, batch 8, dropout {dropout:g}, one epoch of {n_b8} windows through the host API"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -117,6 +161,7 @@ def main():
     ap.add_argument("--dropout", type=float, default=0.2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
+    ap.add_argument("--no-extras", action="store_true", help="skip the inference and batch-8 side measurements")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -216,6 +261,7 @@ def main():
                         "avg_launch_us": 1000.0 * ms / cnt,
                         "launches": cnt, "flops_per_launch": total_flops / cnt,
                         "rows_per_launch": n_win * args.steps / cnt}
+            roofline["traffic"], roofline["traffic_source"] = measured_traffic(dom, n_win * args.steps / cnt)
         else:
             total_bytes = 1040.0 * n_win * args.steps
             achieved = total_bytes / (ms * 1e-3) / 1e9
@@ -258,6 +304,8 @@ def main():
         "roofline": roofline,
         "kernels": kernels,
     }
+    if world == 1 and not args.no_extras:
+        out["other_figures"] = other_figures(sz, ext, plan, pcm, feats, (60, H1, H2, C), n_win, dev, args.lr, args.dropout)
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.speakers, (H1, H2), args.seconds)
     print(json.dumps(out))
