@@ -29,8 +29,8 @@ enum Epi {
     EPI_MUL_DTANH = 3,  // C = acc * (1 - aux^2)          (lib.rs:1034)
     EPI_MUL_DRELU = 4,  // C = acc * (aux > 0)            (lib.rs:1039-1040)
     EPI_SLAB = 5,       // C[z] (+)= acc                  (split-K partial)
-    EPI_BIAS_RELU_MASK = 6,  // EPI_BIAS_RELU, and bit (n % 32) of mask[m][n / 32] = (C > 0)
-    EPI_MUL_MASK = 7    // C = acc * bit of mask[m][n / 32]   (same product as EPI_MUL_DRELU)
+    EPI_BIAS_RELU_MASK = 6,  // EPI_BIAS_RELU, and bit (m % 32) of mask[m / 32][n] = (C > 0)
+    EPI_MUL_MASK = 7    // C = acc * bit of mask[m / 32][n]   (same product as EPI_MUL_DRELU)
 };
 
 struct GemmArgs {
@@ -48,7 +48,8 @@ struct GemmArgs {
     int slab_add = 0;   // EPI_SLAB only: add to the slab instead of overwriting it
     int a_pad = 0;      // A's allocation is padded (finite values) up to the tile boundary past M resp. K,
                         // so edge tiles of A may be fetched without bounds checks
-    uint32_t* mask = nullptr;  // EPI_*_MASK: [M][N / 32] sign bits of the ReLU layer (N % 32 == 0)
+    uint32_t* mask = nullptr;  // EPI_*_MASK: [ceil(M / 32)][N] sign bits of the ReLU layer, one word per
+                               // column and block of 32 rows (what one lane of an MFMA tile holds)
 };
 
 struct Frag4 { float v[4]; };
@@ -288,26 +289,32 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_kernel(GemmArgs g)
             float bias = 0.0f;
             if (EPI == EPI_BIAS_RELU || EPI == EPI_BIAS_TANH || EPI == EPI_BIAS || EPI == EPI_BIAS_RELU_MASK)
                 bias = g.bias[col];
-            const int mask_ld = g.N >> 5;
+            // One MFMA tile is 32 rows x 32 columns; a lane holds column `col` and the 16 rows
+            // (r & 3) + 8 (r >> 2) + 4 half.  Its 16 sign bits and those of lane ^ 32 make the
+            // mask word of (row block, col).
+            const size_t mask_at = (size_t)((m0 + wm * 64 + tm * 32) >> 5) * g.N + col;
+            uint32_t mword = 0;
+            if (EPI == EPI_MUL_MASK) mword = g.mask[mask_at];
+            if (EPI == EPI_BIAS_RELU_MASK) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (acc[tm][tn][r] + bias > 0.0f) mword |= 1u << ((r & 3) + 8 * (r >> 2) + 4 * half);
+                mword |= (uint32_t)__shfl_xor((int)mword, 32);
+                if (half == 0) g.mask[mask_at] = mword;
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int rbit = (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int row = m0 + wm * 64 + tm * 32 + rbit;
                 float v = acc[tm][tn][r];
-                if (EPI == EPI_BIAS_RELU_MASK) {
-                    // whole wave takes part: lanes 0-31 hold 32 columns of `row`, lanes 32-63 of row + 4
-                    v += bias;
-                    const unsigned long long pos = __ballot(v > 0.0f);
-                    if (l31 == 0 && row < g.M)
-                        g.mask[(size_t)row * mask_ld + (col >> 5)] = (uint32_t)(half ? pos >> 32 : pos);
-                    v = v > 0.0f ? v : 0.0f;
-                }
+                if (EPI == EPI_BIAS_RELU_MASK) { v += bias; v = v > 0.0f ? v : 0.0f; }
                 if (row >= g.M) continue;
                 if (EPI == EPI_BIAS_RELU) { v += bias; v = v > 0.0f ? v : 0.0f; }
                 else if (EPI == EPI_BIAS_TANH) v = fast_tanh(v + bias);
                 else if (EPI == EPI_BIAS) v += bias;
                 else if (EPI == EPI_MUL_DTANH) { const float h = g.aux[(size_t)row * g.ldaux + col]; v *= (1.0f - h * h); }
                 else if (EPI == EPI_MUL_DRELU) { const float h = g.aux[(size_t)row * g.ldaux + col]; v *= (h > 0.0f ? 1.0f : 0.0f); }
-                else if (EPI == EPI_MUL_MASK) { if (!((g.mask[(size_t)row * mask_ld + (col >> 5)] >> l31) & 1u)) v = 0.0f; }
+                else if (EPI == EPI_MUL_MASK) { if (!((mword >> rbit) & 1u)) v = 0.0f; }
                 C[(size_t)row * g.ldc + col] = v;
             }
         }

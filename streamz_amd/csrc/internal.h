@@ -61,7 +61,7 @@ struct Workspace {
     float *xd = nullptr, *h1 = nullptr, *h2 = nullptr, *p = nullptr, *d2 = nullptr, *d1 = nullptr, *slab = nullptr,
           *w2t = nullptr;
     uint8_t* live = nullptr;
-    uint32_t* mask = nullptr;     // [rows][hidden1 / 32] sign bits of the first layer
+    uint32_t* mask = nullptr;     // [rows / 32][hidden1] sign bits of the first layer
     double* stat_slab = nullptr;  // per-workgroup {loss, live rows} partials of the head kernels
     uint64_t slab_floats = 0;
     // regions of `slab` (float offsets): split-K partials of dW1|db1, dW2, dW3|db3 and db2

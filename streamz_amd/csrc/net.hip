@@ -825,7 +825,7 @@ int ensure_workspace(Net* n, uint64_t rows)
     SZ_HIP(hipMalloc((void**)&w.d1, R * n->h1 * sizeof(float)));
     SZ_HIP(hipMalloc((void**)&w.slab, w.slab_floats * sizeof(float)));
     SZ_HIP(hipMalloc((void**)&w.live, R));
-    SZ_HIP(hipMalloc((void**)&w.mask, R * ((n->h1 + 31) / 32) * sizeof(uint32_t)));
+    SZ_HIP(hipMalloc((void**)&w.mask, ((R + 127) / 128 * 4) * (uint64_t)n->h1 * sizeof(uint32_t)));
     SZ_HIP(hipMalloc((void**)&w.stat_slab, 2 * head_blocks * sizeof(double)));
     SZ_HIP(hipMalloc((void**)&w.w2t, ((uint64_t)n->h1 * n->h2 + 2 * 64 * 4 * ((n->h2 + 15) / 16)) * sizeof(float)));
     w.rows = R;
@@ -1105,8 +1105,8 @@ int net_accumulate(Net* n, const AccumArgs& a, hipStream_t s)
                            (int)n->in, a.skip_zero_rows ? 1 : 0, w.xd, w.ldx, w.live);
         }
         SZ_HIP(hipGetLastError());
-        // with hidden1 a multiple of 32 the ReLU derivative travels as one bit per unit
-        uint32_t* relu_mask = (n->h1 % 32) == 0 ? w.mask : nullptr;
+        // the ReLU derivative travels as one bit per unit
+        uint32_t* relu_mask = w.mask;
         rc = forward_hidden(n, w.xd, R, false, s, relu_mask, w.ldx);
         if (rc) return rc;
         if (use_head) {
