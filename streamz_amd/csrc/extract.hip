@@ -29,7 +29,7 @@ __device__ __forceinline__ void wave_sync()
 
 constexpr int kBaseThreads = 256;
 constexpr int kBaseWaves = kBaseThreads / 64;
-constexpr size_t kBaseLdsBytes = (size_t)kBaseWaves * kWinPerWave * kRegionFloats * sizeof(float);
+constexpr size_t kBaseLdsBytes = (size_t)kBaseWaves * kWinPerWave * kRegionStride * sizeof(float);
 
 __global__ __launch_bounds__(kBaseThreads, 2) void mfcc_base_kernel(const int16_t* __restrict__ pcm,
                                                                   const Segment* __restrict__ segs,
@@ -44,7 +44,7 @@ __global__ __launch_bounds__(kBaseThreads, 2) void mfcc_base_kernel(const int16_
     const int slot = lane < 60 ? lane : lane - 10;
     const int grp = slot / kGroup;
     const int u = slot - grp * kGroup;
-    float* R = lds + (wave * kWinPerWave + grp) * kRegionFloats;
+    float* R = lds + (wave * kWinPerWave + grp) * kRegionStride;
     const uint32_t waves_total = gridDim.x * kBaseWaves;
     for (uint32_t sg = blockIdx.x * kBaseWaves + wave; sg < n_segs; sg += waves_total) {
         const Segment S = segs[sg];

@@ -8,8 +8,11 @@
 // Scratch region R, in floats (kRegionFloats per window):
 //   [0, 800)    Y[k1][n2] complex, row stride 40 floats       (phase 1 -> phase 2)
 //   [0, 404)    power spectrum P[0..400]                      (phase 2 -> phase 3; aliases Y)
-//   [404, 724)  mel partial sums, (fall, rise) pairs          (phase 3 -> phase 4)
-//   [724, 750)  log mel energies                              (phase 4 -> phase 5)
+//   [404, 734)  mel partial sums, (fall, rise) pairs, lane q at 404 + 33 q (an odd stride, so
+//               that the ten lanes hit different LDS banks)   (phase 3 -> phase 4)
+//   [736, 762)  log mel energies                              (phase 4 -> phase 5)
+// On the device consecutive windows' regions start kRegionStride floats apart, which shifts
+// each window by 4 banks against its neighbour.
 #pragma once
 #include <math.h>
 #include <stdint.h>
@@ -20,9 +23,11 @@
 namespace sz {
 
 constexpr int kRegionFloats = 800;
+constexpr int kRegionStride = 804;
 constexpr int kRowFloats = 40;
 constexpr int kPartOff = 404;
-constexpr int kLogOff = 724;
+constexpr int kLogOff = 736;
+static_assert(kPartOff + kGroup * kPairStride <= kLogOff && kLogOff + kMels <= kRegionFloats, "region layout");
 
 struct alignas(8) pcm4 { int16_t s[4]; };
 struct alignas(16) f4 { float v[4]; };
@@ -141,8 +146,8 @@ SZ_HD void phase3(int q, float* R, const ExtractTables* T)
         af += ms.wf * p;
         ar += ms.wr * p;
         if (ms.flush) {
-            R[kPartOff + (q * kMaxPairs + pair) * 2 + 0] = af;
-            R[kPartOff + (q * kMaxPairs + pair) * 2 + 1] = ar;
+            R[kPartOff + q * kPairStride + pair * 2 + 0] = af;
+            R[kPartOff + q * kPairStride + pair * 2 + 1] = ar;
             ++pair;
             af = 0.0f;
             ar = 0.0f;

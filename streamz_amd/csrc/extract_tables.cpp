@@ -112,7 +112,7 @@ int build_extract_tables(ExtractTables* t)
             ms.flush = last ? 1 : 0;
             if (last) {
                 if (pair >= kMaxPairs) return -4;
-                const int base = (q * kMaxPairs + pair) * 2;
+                const int base = q * kPairStride + pair * 2;
                 if (i >= 1) fall_pos[i - 1].push_back(base + 0);
                 if (i < kMels) rise_pos[i].push_back(base + 1);
                 ++pair;

@@ -33,6 +33,7 @@ constexpr int kWinPerWave = 6;    // windows per wavefront iteration
 constexpr int kSplitSlots = 21;
 constexpr int kMelSteps = 40;
 constexpr int kMaxPairs = 16;     // partial (fall, rise) pairs per mel lane
+constexpr int kPairStride = 2 * kMaxPairs + 1;  // floats between two lanes' partial arrays (odd: no bank clash)
 constexpr int kMaxComb = 8;
 
 struct MelStep {
