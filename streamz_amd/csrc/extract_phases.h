@@ -7,10 +7,10 @@
 //
 // Scratch region R, in floats (kRegionFloats per window):
 //   [0, 800)    Y[k1][n2] complex, row stride 40 floats       (phase 1 -> phase 2)
-//   [0, 404)    power spectrum P[0..400]                      (phase 2 -> phase 3; aliases Y)
-//   [404, 734)  mel partial sums, (fall, rise) pairs, lane q at 404 + 33 q (an odd stride, so
+//   [0, 410)    power spectrum, bin k at pslot(k)             (phase 2 -> phase 3; aliases Y)
+//   [412, 742)  mel partial sums, (fall, rise) pairs, lane q at 412 + 33 q (an odd stride, so
 //               that the ten lanes hit different LDS banks)   (phase 3 -> phase 4)
-//   [736, 762)  log mel energies                              (phase 4 -> phase 5)
+//   [744, 770)  log mel energies                              (phase 4 -> phase 5)
 // On the device consecutive windows' regions start kRegionStride floats apart, which shifts
 // each window by 4 banks against its neighbour.
 #pragma once
@@ -25,8 +25,8 @@ namespace sz {
 constexpr int kRegionFloats = 800;
 constexpr int kRegionStride = 804;
 constexpr int kRowFloats = 40;
-constexpr int kPartOff = 404;
-constexpr int kLogOff = 736;
+constexpr int kPartOff = 412;
+constexpr int kLogOff = 744;
 static_assert(kPartOff + kGroup * kPairStride <= kLogOff && kLogOff + kMels <= kRegionFloats, "region layout");
 
 struct alignas(8) pcm4 { int16_t s[4]; };
@@ -126,29 +126,37 @@ SZ_HD void phase2(int u, float* R, const ExtractTables* T)
         const v2f w = mk(T->sw[s][u][0], T->sw[s][u][1]);
         float pk, pn;
         split_pair(P, Q, w, pk, pn);
-        const int k = T->kb[s][u];
         if (s < 20 || z) {
-            R[k] = pk;
-            R[400 - k] = pn;
+            R[T->pk[s][u][0]] = pk;
+            R[T->pk[s][u][1]] = pn;
         }
     }
 }
 
-// Phase 3: this lane's 40 bins of the mel sweep.
+// Phase 3: this lane's 40 bins of the mel sweep.  Fully unrolled: the 40 weight pairs and the
+// 40 power values are requested up front, the flush points come from a per-lane bit mask.
 SZ_HD void phase3(int q, float* R, const ExtractTables* T)
 {
-    float af = 0.0f, ar = 0.0f;
-    int pair = 0;
-#pragma unroll 8
+    const uint64_t flush = T->mel_flush[q];
+    float wf[kMelSteps], wr[kMelSteps], p[kMelSteps];
+#pragma unroll
     for (int st = 0; st < kMelSteps; ++st) {
-        const MelStep ms = T->mel[st][q];
-        const float p = R[kMelSteps * q + 1 + st];
-        af += ms.wf * p;
-        ar += ms.wr * p;
-        if (ms.flush) {
-            R[kPartOff + q * kPairStride + pair * 2 + 0] = af;
-            R[kPartOff + q * kPairStride + pair * 2 + 1] = ar;
-            ++pair;
+        wf[st] = T->melw[st][q][0];
+        wr[st] = T->melw[st][q][1];
+    }
+#pragma unroll
+    for (int st = 0; st < kMelSteps; ++st) p[st] = R[(kMelSteps + 1) * q + 1 + st];  // pslot(40 q + 1 + st)
+    float af = 0.0f, ar = 0.0f;
+    float* out = R + kPartOff + q * kPairStride;
+    if (q == 0) out[kZeroSlot] = 0.0f;  // what the unused recombination entries point at
+#pragma unroll
+    for (int st = 0; st < kMelSteps; ++st) {
+        af += wf[st] * p[st];
+        ar += wr[st] * p[st];
+        if ((flush >> st) & 1) {
+            out[0] = af;
+            out[1] = ar;
+            out += 2;
             af = 0.0f;
             ar = 0.0f;
         }
@@ -156,18 +164,28 @@ SZ_HD void phase3(int q, float* R, const ExtractTables* T)
 }
 
 // Phase 4: recombine the partial sums of filters q, q+10, q+20 and take the clamped log
-// (lib.rs:309).
+// (lib.rs:309).  Every filter reads kMaxComb slots; the unused ones hold 0.
 SZ_HD void phase4(int q, float* R, const ExtractTables* T)
 {
+    int pos[3][kMaxComb];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const int m = q + 10 * r < kMels ? q + 10 * r : 0;
+#pragma unroll
+        for (int i = 0; i < kMaxComb; ++i) pos[r][i] = T->comb_pos[m][i];
+    }
+    float v[3][kMaxComb];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int i = 0; i < kMaxComb; ++i) v[r][i] = R[kPartOff + pos[r][i]];
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
         const int m = q + 10 * r;
-        if (m < kMels) {
-            float s = 0.0f;
-            const int n = T->comb_n[m];
-            for (int i = 0; i < n; ++i) s += R[kPartOff + T->comb_pos[m][i]];
-            R[kLogOff + m] = logf(fmaxf(s, 1e-12f));
-        }
+        float s = 0.0f;
+#pragma unroll
+        for (int i = 0; i < kMaxComb; ++i) s += v[r][i];
+        if (m < kMels) R[kLogOff + m] = logf(fmaxf(s, 1e-12f));
     }
 }
 

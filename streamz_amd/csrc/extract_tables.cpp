@@ -77,6 +77,8 @@ int build_extract_tables(ExtractTables* t)
             if (u == 0) k = s <= 10 ? 20 * s : (s <= 19 ? 10 + 20 * s : 190);
             else k = s <= 19 ? u + 20 * s : u;  // slot 20 is idle for u != 0
             t->kb[s][u] = k;
+            t->pk[s][u][0] = pslot(k);
+            t->pk[s][u][1] = pslot(400 - k);
             put(t->sw[s][u], (double)k / 800.0, 1.0);
         }
 
@@ -110,6 +112,9 @@ int build_extract_tables(ExtractTables* t)
             ms.wr = i < kMels ? t->mel_dense[i][k] : 0.0f;
             const bool last = st == kMelSteps - 1 || interval[k + 1] != i;
             ms.flush = last ? 1 : 0;
+            t->melw[st][q][0] = ms.wf;
+            t->melw[st][q][1] = ms.wr;
+            if (last) t->mel_flush[q] |= 1ull << st;
             if (last) {
                 if (pair >= kMaxPairs) return -4;
                 const int base = q * kPairStride + pair * 2;
@@ -124,6 +129,7 @@ int build_extract_tables(ExtractTables* t)
         for (int p : rise_pos[m]) { if (n >= kMaxComb) return -5; t->comb_pos[m][n++] = p; }
         for (int p : fall_pos[m]) { if (n >= kMaxComb) return -5; t->comb_pos[m][n++] = p; }
         t->comb_n[m] = n;
+        for (; n < kMaxComb; ++n) t->comb_pos[m][n] = kZeroSlot;
     }
 
     // DCT-II without the factor 2 (rustdct), first 20 outputs

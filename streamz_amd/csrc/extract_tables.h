@@ -35,6 +35,11 @@ constexpr int kMelSteps = 40;
 constexpr int kMaxPairs = 16;     // partial (fall, rise) pairs per mel lane
 constexpr int kPairStride = 2 * kMaxPairs + 1;  // floats between two lanes' partial arrays (odd: no bank clash)
 constexpr int kMaxComb = 8;
+constexpr int kZeroSlot = 2 * kMaxPairs;  // relative to lane 0's partial array: its padding float, kept 0
+
+// Slot of power bin k (0..400) in a window's scratch region: k plus the number of complete
+// 40-bin runs before it, so that lanes sweeping neighbouring runs hit different LDS banks.
+constexpr int pslot(int k) { return k <= 40 ? k : k + (k - 1) / 40; }
 
 struct MelStep {
     float wf;       // weight into the falling-edge accumulator
@@ -47,10 +52,14 @@ struct ExtractTables {
     float twa[20][kGroup][2];
     float twb[20][kGroup][2];
     float sw[kSplitSlots][kGroup][2];
-    int32_t kb[kSplitSlots][kGroup];
+    int32_t kb[kSplitSlots][kGroup];      // bin k handled by (slot, lane); its partner is 400 - k
+    int32_t pk[kSplitSlots][kGroup][2];   // where those two bins live in the region: pslot(k), pslot(400 - k)
     MelStep mel[kMelSteps][kGroup];
+    float melw[kMelSteps][kGroup][2];     // (wf, wr) of mel[][], for one 8-byte load per step
+    uint64_t mel_flush[kGroup];           // bit st set: mel[st][q].flush
     int32_t comb_n[32];
-    int32_t comb_pos[32][kMaxComb];   // float index into a window's partial array
+    // float index into a window's partial array; entries past comb_n point at a slot that holds 0
+    alignas(16) int32_t comb_pos[32][kMaxComb];
     float dct2[kMels][kGroup][2];     // (D[q][n], D[q+10][n]),  D[c][n] = cos(pi*(2n+1)*c/52)
     float mel_dense[kMels][kBins];    // the full filterbank, kept for inspection / tests
 };

@@ -46,14 +46,14 @@ int main(int argc, char** argv)
         for (int s = 0; s < kSplitSlots; ++s) {
             if (s == 20 && u != 0) continue;
             int k = T.kb[s][u];
-            Pm[k] = tmp[k];
-            Pm[400 - k] = tmp[400 - k];
+            Pm[k] = tmp[pslot(k)];
+            Pm[400 - k] = tmp[pslot(400 - k)];
         }
     }
     for (int i = 0; i < kBins; ++i) {
         if (std::isnan(Pm[i])) { std::printf("bin %d never written\n", i); return 3; }
-        R[i] = Pm[i];
     }
+    for (int i = 0; i < kBins; ++i) R[pslot(i)] = Pm[i];
     // direct evaluation
     std::vector<double> pw(kBins);
     double pmax = 0;
@@ -70,7 +70,7 @@ int main(int argc, char** argv)
     }
     double e_pow = 0;
     for (int k = 0; k < kBins; ++k) {
-        double e = std::fabs((double)R[k] - pw[k]) / pmax;
+        double e = std::fabs((double)R[pslot(k)] - pw[k]) / pmax;
         if (e > e_pow) e_pow = e;
     }
     for (int q = 0; q < kGroup; ++q) phase3(q, R, &T);
