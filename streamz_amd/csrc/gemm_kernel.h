@@ -152,7 +152,7 @@ __device__ __forceinline__ void fetch_krows_fast(const float* base, int ld, int 
 
 // TAG only separates instantiations, so that each call site is its own kernel in a profile.
 // TM = rows of the block tile, KT = K tile (16 or 32), DB = double-buffered LDS tiles.
-template <int AM, int BMd, int EPI, int TAG, int TM, int KT, int DB, int DBG = 0>
+template <int AM, int BMd, int EPI, int TAG, int TM, int KT, int DB>
 __global__ __launch_bounds__(kGemmThreads) void gemm_kernel(GemmArgs g)
 {
     constexpr int BK = KT;
@@ -215,16 +215,14 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_kernel(GemmArgs g)
     const bool b_inside = g.b_vec && n0 + BN <= g.N;
     auto fetch = [&](int k0) {
         const bool k_inside = k0 + BK <= k_end;
-        if ((DBG & 16) && k0 != k_begin) {
-        } else if (a_inside && (k_inside || (AM == A_ROWS && g.a_pad))) {
+        if (a_inside && (k_inside || (AM == A_ROWS && g.a_pad))) {
             if (AM == A_ROWS) fetch_rows_fast<TM, BK>(g.A, g.lda, m0, k0, fa);
             else fetch_krows_fast<TM, BK>(g.A, g.lda, m0, k0, fa);
         } else {
             if (AM == A_ROWS) fetch_rows<TM, BK>(g.A, g.lda, m0, g.M, k0, k_end, g.a_vec, fa);
             else fetch_krows<TM, BK>(g.A, g.lda, m0, a_cols, k0, k_end, g.a_vec, g.ones_row, fa);
         }
-        if ((DBG & 32) && k0 != k_begin) {
-        } else if (b_inside && k_inside) {
+        if (b_inside && k_inside) {
             if (BMd == B_ROWS) fetch_rows_fast<BN, BK>(g.B, g.ldb, n0, k0, fb);
             else fetch_krows_fast<BN, BK>(g.B, g.ldb, n0, k0, fb);
         } else {
@@ -242,27 +240,25 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_kernel(GemmArgs g)
     if (DB && k_begin < k_end) { stash(0); __syncthreads(); }
     int buf = 0;
     for (int k0 = k_begin; k0 < k_end; k0 += BK) {
-        if (!DB && (!(DBG & 1) || k0 == k_begin)) {
-            if (!(DBG & 4) || k0 == k_begin) __syncthreads();
-            if (!(DBG & 8) || k0 == k_begin) stash(0);
-            if (!(DBG & 4) || k0 == k_begin) __syncthreads();
+        if (!DB) {
+            __syncthreads();
+            stash(0);
+            __syncthreads();
         }
-        if (!(DBG & 1) && k0 + BK < k_end) fetch(k0 + BK);
+        if (k0 + BK < k_end) fetch(k0 + BK);
         const float* As = As_ + buf * BK * LDT;
         const float* Bs = Bs_ + buf * BK * LDT;
         // fragments of k-step kk+2 are read from LDS while the MFMAs of k-step kk run
         const float* ar = As + half * LDA + wm * 64 + l31;
         const float* br = Bs + half * LDB + wn * WN + l31;
         float fa0[2], fa1[2], fbn[2][TN];
-        if (!((DBG & 2) && k0 != k_begin)) {
         fa0[0] = ar[0]; fa1[0] = ar[32];
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) fbn[0][tn] = br[32 * tn];
-        }
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
             const int cur = (kk >> 1) & 1, nxt = cur ^ 1;
-            if (kk + 2 < BK && !((DBG & 2) && k0 != k_begin)) {
+            if (kk + 2 < BK) {
                 fa0[nxt] = ar[(kk + 2) * LDA]; fa1[nxt] = ar[(kk + 2) * LDA + 32];
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn) fbn[nxt][tn] = br[(kk + 2) * LDB + 32 * tn];

@@ -11,15 +11,15 @@ using namespace sz::gemm;
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { std::printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); std::exit(1); } } while (0)
 
-template <int AM, int BMd, int EPI, int TM, int KT, int DB, int DBG = 0>
+template <int AM, int BMd, int EPI, int TM, int KT, int DB>
 float run(GemmArgs g, int splits, int iters)
 {
     dim3 grid((g.N + BN - 1) / BN, (g.M + TM - 1) / TM, splits);
     hipEvent_t a, b;
     CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
-    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((gemm_kernel<AM, BMd, EPI, 0, TM, KT, DB, DBG>), grid, dim3(kGemmThreads), 0, 0, g);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((gemm_kernel<AM, BMd, EPI, 0, TM, KT, DB>), grid, dim3(kGemmThreads), 0, 0, g);
     CK(hipEventRecord(a));
-    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((gemm_kernel<AM, BMd, EPI, 0, TM, KT, DB, DBG>), grid, dim3(kGemmThreads), 0, 0, g);
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((gemm_kernel<AM, BMd, EPI, 0, TM, KT, DB>), grid, dim3(kGemmThreads), 0, 0, g);
     CK(hipEventRecord(b));
     CK(hipEventSynchronize(b));
     float ms = 0;
@@ -37,32 +37,10 @@ void variant(float* X, float* H1, float* H2, float* D2, float* D1, float* W1, fl
     g = GemmArgs{}; g.A = X; g.lda = IN; g.B = W1; g.ldb = H1n; g.C = H1; g.ldc = H1n; g.M = R; g.N = H1n; g.K = IN; g.k_chunk = IN; g.bias = bias;
     g.a_vec = vec(g.A, g.lda); g.b_vec = vec(g.B, g.ldb);
     float t1 = run<A_ROWS, B_KROWS, EPI_BIAS_RELU, 128, KT, DB>(g, 1, 20);
-    if (KT == 32 && DB == 0) {
-        float f1 = run<A_ROWS, B_KROWS, EPI_BIAS_RELU, 128, KT, DB, 64>(g, 1, 20);
-        float f2 = run<A_ROWS, B_KROWS, EPI_BIAS_RELU, 128, KT, DB, 1>(g, 1, 20);
-        float f3 = run<A_ROWS, B_KROWS, EPI_BIAS_RELU, 128, KT, DB, 65>(g, 1, 20);
-        std::printf("  fwd1 full %.1f | no stores %.1f | no refetch %.1f | neither %.1f\n", t1, f1, f2, f3);
-    }
     // fwd2
     g = GemmArgs{}; g.A = H1; g.lda = H1n; g.B = W2; g.ldb = H2n; g.C = H2; g.ldc = H2n; g.M = R; g.N = H2n; g.K = H1n; g.k_chunk = H1n; g.bias = bias;
     g.a_vec = vec(g.A, g.lda); g.b_vec = vec(g.B, g.ldb);
     float t2 = run<A_ROWS, B_KROWS, EPI_BIAS_TANH, 128, KT, DB>(g, 1, 20);
-    if (KT == 32 && DB == 0) {
-        float d1 = run<A_ROWS, B_KROWS, EPI_BIAS_TANH, 128, KT, DB, 1>(g, 1, 20);
-        float d2 = run<A_ROWS, B_KROWS, EPI_BIAS_TANH, 128, KT, DB, 2>(g, 1, 20);
-        float d3 = run<A_ROWS, B_KROWS, EPI_BIAS_TANH, 128, KT, DB, 3>(g, 1, 20);
-        float d4 = run<A_ROWS, B_KROWS, EPI_BIAS, 128, KT, DB, 0>(g, 1, 20);
-        float e4 = run<A_ROWS, B_KROWS, EPI_BIAS, 128, KT, DB, 16>(g, 1, 20);
-        float e5 = run<A_ROWS, B_KROWS, EPI_BIAS, 128, KT, DB, 32>(g, 1, 20);
-        float e6 = run<A_ROWS, B_KROWS, EPI_BIAS, 128, KT, DB, 48>(g, 1, 20);
-        std::printf("  no tanh: no A fetch %.1f | no B fetch %.1f | no A, no B fetch (stash+barriers stay) %.1f\n", e4, e5, e6);
-        float e1 = run<A_ROWS, B_KROWS, EPI_BIAS, 128, KT, DB, 4>(g, 1, 20);
-        float e2 = run<A_ROWS, B_KROWS, EPI_BIAS, 128, KT, DB, 8>(g, 1, 20);
-        float e3 = run<A_ROWS, B_KROWS, EPI_BIAS, 128, KT, DB, 12>(g, 1, 20);
-        std::printf("  no tanh: full %.1f | no barriers %.1f | no stash %.1f | no barriers, no stash (fetch only) %.1f\n", d4, e1, e2, e3);
-        float d5 = run<A_ROWS, B_KROWS, EPI_BIAS, 128, KT, DB, 3>(g, 1, 20);
-        std::printf("  fwd2 full %.1f | no global/stash %.1f | no LDS reads %.1f | neither %.1f | no tanh %.1f | neither+no tanh %.1f\n", t2, d1, d2, d3, d4, d5);
-    }
     // delta1
     g = GemmArgs{}; g.A = D2; g.lda = H2n; g.B = W2 /* read as w2^T [256][512] */; g.ldb = H1n; g.C = D1; g.ldc = H1n; g.M = R; g.N = H1n; g.K = H2n; g.k_chunk = H2n; g.aux = H1; g.ldaux = H1n;
     g.a_vec = vec(g.A, g.lda); g.b_vec = vec(g.B, g.ldb);
