@@ -13,6 +13,7 @@
 #include <new>
 
 #include "internal.h"
+#include "rng.h"
 #include "npy.h"
 #include "streamz_hip.h"
 #include "wav.h"
@@ -48,14 +49,6 @@ struct DevBuf {
     }
     template <class T> T* as() { return static_cast<T*>(p); }
 };
-
-inline uint64_t mix64(uint64_t z)
-{
-    z += 0x9E3779B97F4A7C15ull;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    return z ^ (z >> 31);
-}
 
 int extract_files_host(Extractor* e, const int16_t* const* pcm, const uint64_t* n_samples, uint32_t n_files,
                        float* const* out)
@@ -165,7 +158,7 @@ int pretrain_host(Net* n, const float* windows, uint64_t n_win, uint32_t target_
     const uint64_t seed = rng ? rng->seed : 0x5A17ull;
     std::vector<uint32_t> order(n_win);
     uint64_t draw = 0;
-    for (uint32_t ep = 0; ep < epochs; ++ep) {
+    auto shuffle_epoch = [&](uint32_t ep) -> int {
         if (rng && rng->perm) {
             std::memcpy(order.data(), rng->perm + (size_t)ep * n_win, n_win * sizeof(uint32_t));
             for (uint64_t i = 0; i < n_win; ++i)
@@ -177,28 +170,62 @@ int pretrain_host(Net* n, const float* windows, uint64_t n_win, uint32_t target_
                 std::swap(order[i - 1], order[j]);
             }
         }
-        SZ_HIP(hipMemcpyAsync(d_perm.p, order.data(), n_win * sizeof(uint32_t), hipMemcpyHostToDevice, nullptr));
-        if (have_keep)
-            SZ_HIP(hipMemcpyAsync(d_keep.p, rng->keep + (size_t)ep * n_win * kFeat, n_win * kFeat,
-                                  hipMemcpyHostToDevice, nullptr));
-        SZ_HIP(hipStreamSynchronize(nullptr));  // `order` is reused by the next epoch
-        for (uint64_t c0 = 0; c0 < n_win; c0 += bs) {
-            AccumArgs a;
-            a.x_dev = d_win.as<float>();
-            a.rows = std::min<uint64_t>(bs, n_win - c0);
-            a.perm_dev = d_perm.as<uint32_t>() + c0;
-            a.keep_dev = have_keep ? d_keep.as<uint8_t>() + c0 * kFeat : nullptr;
-            a.dropout = dropout;
-            a.seed = seed;
-            a.row_counter0 = (uint64_t)ep * n_win + c0;
-            a.target_dev = d_tgt.as<float>();
-            a.skip_zero_rows = true;
-            rc = net_zero_grad(n, nullptr);
+        return SZH_OK;
+    };
+    const uint64_t steps_per_epoch = (n_win + bs - 1) / bs;
+    // Batches of up to 8 rows (the reference's CLI uses 8) run as one resident kernel per group of
+    // epochs: all their shuffles (and injected masks) are uploaded first.
+    const uint64_t group = std::max<uint64_t>(1, std::min<uint64_t>(epochs, (16ull << 20) / n_win));
+    if (step_kernel_applies(n, (uint32_t)bs, group * steps_per_epoch)) {
+        DevBuf d_perms, d_keeps;
+        rc = d_perms.alloc(group * n_win * sizeof(uint32_t));
+        if (rc) return rc;
+        if (have_keep) { rc = d_keeps.alloc(group * n_win * kFeat); if (rc) return rc; }
+        std::vector<uint32_t> orders(group * n_win);
+        for (uint32_t ep0 = 0; ep0 < epochs; ep0 += (uint32_t)group) {
+            const uint32_t ne = (uint32_t)std::min<uint64_t>(group, epochs - ep0);
+            for (uint32_t e = 0; e < ne; ++e) {
+                rc = shuffle_epoch(ep0 + e);
+                if (rc) return rc;
+                std::memcpy(orders.data() + (size_t)e * n_win, order.data(), n_win * sizeof(uint32_t));
+            }
+            SZ_HIP(hipMemcpy(d_perms.p, orders.data(), (size_t)ne * n_win * sizeof(uint32_t), hipMemcpyHostToDevice));
+            if (have_keep)
+                SZ_HIP(hipMemcpy(d_keeps.p, rng->keep + (size_t)ep0 * n_win * kFeat, (size_t)ne * n_win * kFeat,
+                                 hipMemcpyHostToDevice));
+            // the dropout stream is keyed by (seed, epoch * n_win + position, feature)
+            rc = net_pretrain_steps(n, d_win.as<float>(), (uint32_t)n_win, d_perms.as<uint32_t>(),
+                                    have_keep ? d_keeps.as<uint8_t>() : nullptr, dropout, mix64(seed + ep0), d_tgt.as<float>(),
+                                    ne, (uint32_t)bs, lr, nullptr);
             if (rc) return rc;
-            rc = net_accumulate(n, a, nullptr);
+        }
+    } else {
+        for (uint32_t ep = 0; ep < epochs; ++ep) {
+            rc = shuffle_epoch(ep);
             if (rc) return rc;
-            rc = net_apply(n, lr, nullptr);
-            if (rc) return rc;
+            SZ_HIP(hipMemcpyAsync(d_perm.p, order.data(), n_win * sizeof(uint32_t), hipMemcpyHostToDevice, nullptr));
+            if (have_keep)
+                SZ_HIP(hipMemcpyAsync(d_keep.p, rng->keep + (size_t)ep * n_win * kFeat, n_win * kFeat,
+                                      hipMemcpyHostToDevice, nullptr));
+            SZ_HIP(hipStreamSynchronize(nullptr));  // `order` is reused by the next epoch
+            for (uint64_t c0 = 0; c0 < n_win; c0 += bs) {
+                AccumArgs a;
+                a.x_dev = d_win.as<float>();
+                a.rows = std::min<uint64_t>(bs, n_win - c0);
+                a.perm_dev = d_perm.as<uint32_t>() + c0;
+                a.keep_dev = have_keep ? d_keep.as<uint8_t>() + c0 * kFeat : nullptr;
+                a.dropout = dropout;
+                a.seed = seed;
+                a.row_counter0 = (uint64_t)ep * n_win + c0;
+                a.target_dev = d_tgt.as<float>();
+                a.skip_zero_rows = true;
+                rc = net_zero_grad(n, nullptr);
+                if (rc) return rc;
+                rc = net_accumulate(n, a, nullptr);
+                if (rc) return rc;
+                rc = net_apply(n, lr, nullptr);
+                if (rc) return rc;
+            }
         }
     }
     rc = net_zero_grad(n, nullptr);  // folds the last step's loss into the running totals

@@ -121,6 +121,12 @@ int net_zero_grad(Net* n, hipStream_t s);
 int net_accumulate(Net* n, const AccumArgs& a, hipStream_t s);
 int net_apply(Net* n, float lr, hipStream_t s);
 int net_reset_totals(Net* n, hipStream_t s);
+// The reference's batch-of-8 schedule as one resident kernel (step.hip).  `applies` says whether
+// the network and batch size fit it; d_perm / d_keep hold every epoch's shuffle / dropout mask.
+bool step_kernel_applies(const Net* n, uint32_t batch_size, uint64_t n_steps);
+int net_pretrain_steps(Net* n, const float* d_win, uint32_t n_win, const uint32_t* d_perm, const uint8_t* d_keep,
+                       float dropout, uint64_t seed, const float* d_target, uint32_t epochs, uint32_t batch_size,
+                       float lr, hipStream_t s);
 int net_read_totals(Net* n, hipStream_t s, double* loss_sum, double* live_rows);
 int net_vote_dev(Net* n, const float* x_dev, uint64_t rows, float threshold, unsigned long long* counts_dev, hipStream_t s);
 

@@ -14,6 +14,7 @@
 #include "gemm_kernel.h"
 #include "internal.h"
 #include "prof.h"
+#include "rng.h"
 #include "streamz_hip.h"
 
 namespace sz {
@@ -46,21 +47,6 @@ int launch_gemm(GemmArgs g, int splits, hipStream_t s)
     }
     SZ_HIP(hipGetLastError());
     return SZH_OK;
-}
-
-// ---- counter-based random numbers ----------------------------------------------------
-__host__ __device__ inline uint64_t mix64(uint64_t z)
-{
-    z += 0x9E3779B97F4A7C15ull;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    return z ^ (z >> 31);
-}
-// 24-bit uniform in [0, 1), like rand's gen::<f32>()
-__host__ __device__ inline float uniform01(uint64_t seed, uint64_t a, uint64_t b)
-{
-    const uint64_t h = mix64(mix64(seed ^ (a * 0xD1342543DE82EF95ull)) + b);
-    return (float)(h >> 40) * (1.0f / 16777216.0f);
 }
 
 // ---- row preparation: gather by permutation, input dropout, all-zero flag -------------

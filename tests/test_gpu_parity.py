@@ -189,6 +189,36 @@ def test_pretrain_cli_schedule_small_file(sz, po):
         np.testing.assert_allclose(p, q, atol=1e-4)
 
 
+@pytest.mark.parametrize("dims,batch", [((60, 64, 128, 5), 3), ((60, 512, 256, 16), 8), ((60, 96, 48, 1), 1), ((60, 64, 32, 20), 8)])
+def test_pretrain_resident_step_kernel_edge_cases(sz, po, dims, batch):
+    # batches of <= 8 rows run as one resident kernel (several workgroups, one grid barrier per
+    # step); here with a ragged last batch, one batch whose rows are all dropped to zero (no
+    # update, lib.rs:1003-1005), single dead rows, and three epochs
+    rng = np.random.default_rng(11)
+    n, epochs = 4 * batch + max(1, batch // 2), 3
+    onet = po.Net(*dims)
+    params = [rng.uniform(-0.5, 0.5, s).astype(np.float32) for s in onet.shapes()]
+    onet.set_params(params)
+    net = sz.SimpleNeuralNet(*dims, init=params)
+    wins = rng.standard_normal((n, 60)).astype(np.float32)
+    perm = np.stack([rng.permutation(n) for _ in range(epochs)]).astype(np.uint32)
+    keep = (rng.random((epochs, n, 60)) >= 0.2).astype(np.uint8)
+    keep[0, batch:2 * batch] = 0      # second batch of the first epoch: nothing survives
+    keep[1, 0] = 0                    # one dead row inside a live batch
+    cls = min(1, dims[3] - 1)
+    sz.profile_enable(True)
+    sz.profile_report()
+    loss = sz.pretrain_from_features(net, wins, cls, dims[3], epochs, 0.02, 0.2, batch, perm=perm, keep=keep)
+    tags = sz.profile_report()
+    sz.profile_enable(False)
+    assert "steps" in tags and "fwd2" not in tags, tags  # the resident kernel ran, not the per-layer launches
+    oloss = onet.pretrain_from_features(wins, cls, dims[3], epochs, 0.02, 0.2, batch, perm=perm, keep=keep)
+    assert abs(loss - oloss) < 1e-4 * max(1.0, abs(oloss))
+    for p, q in zip(net.get_params(), onet.get_params()):
+        np.testing.assert_allclose(p, q, atol=1e-4)
+    assert np.isfinite(net.get_flat()).all()
+
+
 def test_pretrain_no_windows_returns_zero(sz):
     net = sz.SimpleNeuralNet(60, 8, 4, 2, seed=1)
     before = net.get_flat()
