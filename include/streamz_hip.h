@@ -146,6 +146,30 @@ int szh_pretrain_from_features(szh_net *net, const float *windows, uint64_t n_wi
                                uint32_t target_class, uint32_t num_classes, uint32_t epochs, float lr,
                                float dropout, uint32_t batch_size, const szh_rng *rng, float *mean_loss);
 
+/* augment, lib.rs:103-116: out[i] = clamp(pcm[(i + shift) % n] * gain + noise[i] * 32767) as i16
+ * (truncating).  noise[n] holds the per-sample draws from (-noise_level, noise_level); NULL ->
+ * drawn from `seed`.  shift < n_samples.  Host buffers. */
+int szh_augment(const int16_t *pcm, uint64_t n_samples, float gain, float noise_level, uint64_t shift,
+                const float *noise, uint64_t seed, int16_t *out);
+
+/* Optional injected augmentation draws for szh_pretrain_network (the reference draws them from
+ * an unseeded thread RNG, lib.rs:104-111).  Any member may be NULL (then drawn from rng->seed):
+ *   gain[epochs], noise_level[epochs], shift[epochs] (taken modulo min(n_samples, 800)),
+ *   noise[epochs][n_samples]. */
+typedef struct szh_aug_draws {
+    const float *gain;
+    const float *noise_level;
+    const uint64_t *shift;
+    const float *noise;
+} szh_aug_draws;
+
+/* pretrain_network, lib.rs:348-397: per epoch the raw samples are augmented, re-extracted,
+ * shuffled and trained on in chunks of batch_size, all on the device.  rng->perm is
+ * [epochs][window_count(n_samples)], rng->keep [epochs][windows][60]. */
+int szh_pretrain_network(szh_net *net, szh_extractor *ext, const int16_t *pcm, uint64_t n_samples,
+                         uint32_t target_class, uint32_t num_classes, uint32_t epochs, float lr, float dropout,
+                         uint32_t batch_size, const szh_aug_draws *aug, const szh_rng *rng, float *mean_loss);
+
 /* train_from_feature_map, lib.rs:632-665: pretrain_from_features over files in list order
  * with num_classes = output_size; feats[f][n_windows[f]][60]; a NULL feats[f] is a file
  * missing from the map and is skipped.  *mean_loss = mean of the per-file losses. */

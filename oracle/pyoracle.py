@@ -62,6 +62,7 @@ def lib():
         L.so_net_train_batch.argtypes = [vp, vp, u64, vp, f32]
         L.so_net_train.argtypes = [vp, vp, vp, f32]
         L.so_seed.argtypes = [u64]
+        L.so_augment.argtypes = [vp, u64, f32, u64, vp, vp]
         L.so_pretrain_from_features.restype = f32
         L.so_pretrain_from_features.argtypes = [vp, vp, u64, u32, u32, u32, f32, f32, u32, vp, vp]
         L.so_identify_from_features.restype = u32
@@ -222,6 +223,16 @@ class Net:
         ids = np.zeros(max(self.out, 1), np.uint32)
         n = lib().so_identify_speaker_list(self._h, ext._h, _p(pcm), pcm.size, float(threshold), fft_mode, _p(ids))
         return ids[:n].copy()
+
+
+def augment(samples, gain, shift, noise):
+    """augment (lib.rs:103-116) with explicit draws; noise[n] are the per-sample values of
+    gen_range(-noise_level..noise_level)."""
+    x = np.ascontiguousarray(samples, np.int16)
+    nz = np.ascontiguousarray(noise, np.float32)
+    out = np.empty_like(x)
+    lib().so_augment(_p(x), x.size, gain, shift, _p(nz), _p(out))
+    return out
 
 
 def seed(s):

@@ -534,6 +534,19 @@ float so_pretrain_from_features(so_net *net, const float *windows, uint64_t n_wi
     return count > 0 ? total_loss / (float)count : 0.0f;
 }
 
+/* augment, lib.rs:103-116, with the random draws passed in: out[i] = clamp(in[(i + shift) % n] *
+ * gain + noise[i] * 32767) truncated to i16 (Rust's `as i16` on an in-range float truncates). */
+void so_augment(const int16_t *in, uint64_t n, float gain, uint64_t shift, const float *noise, int16_t *out)
+{
+    for (uint64_t i = 0; i < n; ++i) {
+        const uint64_t idx = (i + shift) % n;
+        float val = (float)in[idx] * gain + noise[i] * 32767.0f;
+        if (val < -32768.0f) val = -32768.0f;
+        if (val > 32767.0f) val = 32767.0f;
+        out[i] = (int16_t)(int)val;
+    }
+}
+
 /* identify_speaker_list, lib.rs:1383-1411.  ids receives the speaker indices with at
  * least one vote, ordered by vote count descending (stable, so ties keep ascending id).
  * The per-window argmax keeps the LAST maximum (Iterator::max_by). */

@@ -57,6 +57,9 @@ _SIGS = {
     "szh_net_train_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_float]),
     "szh_pretrain_from_features": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32,
                                              C.c_float, C.c_float, C.c_uint32, C.c_void_p, C.POINTER(C.c_float)]),
+    "szh_augment": (C.c_int, [C.c_void_p, C.c_uint64, C.c_float, C.c_float, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p]),
+    "szh_pretrain_network": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32,
+                                       C.c_float, C.c_float, C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]),
     "szh_train_from_feature_map": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
                                              C.c_float, C.c_float, C.c_uint32, C.c_uint64, C.POINTER(C.c_float)]),
     "szh_identify_speaker_list": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_float, C.c_void_p,
@@ -365,6 +368,35 @@ def pretrain_from_features(net, windows, target_class, num_classes, epochs, lr, 
     loss = C.c_float()
     _check(lib().szh_pretrain_from_features(net._h, _p(w), w.shape[0], target_class, num_classes, epochs, lr, dropout,
                                             batch_size, C.byref(rng), C.byref(loss)))
+    return float(loss.value)
+
+
+class _AugDraws(C.Structure):
+    _fields_ = [("gain", C.c_void_p), ("noise_level", C.c_void_p), ("shift", C.c_void_p), ("noise", C.c_void_p)]
+
+
+def augment(samples, gain, noise_level, shift, noise=None, seed=0):
+    """augment (lib.rs:103-116) with explicit draws; noise[n] in (-noise_level, noise_level) or None."""
+    x = np.ascontiguousarray(samples, np.int16)
+    nz = np.ascontiguousarray(noise, np.float32) if noise is not None else None
+    out = np.empty_like(x)
+    _check(lib().szh_augment(_p(x), x.size, gain, noise_level, shift, _p(nz) if nz is not None else None, seed, _p(out)))
+    return out
+
+
+def pretrain_network(net, samples, target_class, num_classes, epochs, lr, dropout, batch_size, extractor,
+                     gain=None, noise_level=None, shift=None, noise=None, perm=None, keep=None, seed=0):
+    """pretrain_network (lib.rs:348-397); every random draw can be injected."""
+    x = np.ascontiguousarray(samples, np.int16)
+    arrs = [np.ascontiguousarray(a, t) if a is not None else None
+            for a, t in ((gain, np.float32), (noise_level, np.float32), (shift, np.uint64), (noise, np.float32))]
+    aug = _AugDraws(*[a.ctypes.data if a is not None else None for a in arrs])
+    pm = np.ascontiguousarray(perm, np.uint32) if perm is not None else None
+    kp = np.ascontiguousarray(keep, np.uint8) if keep is not None else None
+    rng = _Rng(pm.ctypes.data if pm is not None else None, kp.ctypes.data if kp is not None else None, seed)
+    loss = C.c_float()
+    _check(lib().szh_pretrain_network(net._h, extractor._h, _p(x), x.size, target_class, num_classes, epochs, lr, dropout,
+                                      batch_size, C.byref(aug), C.byref(rng), C.byref(loss)))
     return float(loss.value)
 
 

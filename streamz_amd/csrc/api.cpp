@@ -130,34 +130,16 @@ int train_batch_host(Net* n, const float* x, uint64_t B, const float* target, fl
     return SZH_OK;
 }
 
-int pretrain_host(Net* n, const float* windows, uint64_t n_win, uint32_t target_class, uint32_t num_classes,
-                  uint32_t epochs, float lr, float dropout, uint32_t batch_size, const szh_rng* rng, float* mean_loss)
+// Epochs [ep_first, ep_first + n_epochs) of the pretrain loop (lib.rs:599-622) over device-resident
+// windows.  rng's perm / keep arrays are indexed by absolute epoch; `draw` carries the shuffle
+// generator across calls.  Losses are added to the net's running totals.
+int pretrain_epochs_dev(Net* n, const float* d_win, uint64_t n_win, const float* d_tgt, uint32_t ep_first,
+                        uint32_t n_epochs, float lr, float dropout, uint64_t bs, const szh_rng* rng, uint64_t seed,
+                        uint64_t& draw)
 {
-    *mean_loss = 0.0f;
-    if (n->in != (uint32_t)kFeat) { set_error("pretrain_from_features needs a net with 60 inputs"); return SZH_EINVAL; }
-    if (n_win == 0 || epochs == 0 || n->out == 0) return SZH_OK;
-    if (n_win > 0xffffffffull) { set_error("too many windows"); return SZH_EINVAL; }
-    std::lock_guard<std::mutex> lock(n->mu);
-    const uint64_t bs = batch_size > 0 ? batch_size : 1;  // batch_size.max(1), lib.rs:602
-    // one-hot target of width num_classes (lib.rs:592-595), seen through the net's output width
-    std::vector<float> target(n->out, 0.0f);
-    if (target_class < num_classes && target_class < n->out) target[target_class] = 1.0f;
-    DevBuf d_win, d_tgt, d_perm, d_keep;
-    int rc = d_win.alloc(n_win * kFeat * sizeof(float));
-    if (rc) return rc;
-    rc = d_tgt.alloc(n->out * sizeof(float));
-    if (rc) return rc;
-    rc = d_perm.alloc(n_win * sizeof(uint32_t));
-    if (rc) return rc;
+    if (n_win == 0 || n_epochs == 0) return SZH_OK;
     const bool have_keep = rng && rng->keep;
-    if (have_keep) { rc = d_keep.alloc(n_win * kFeat); if (rc) return rc; }
-    SZ_HIP(hipMemcpy(d_win.p, windows, n_win * kFeat * sizeof(float), hipMemcpyHostToDevice));
-    SZ_HIP(hipMemcpy(d_tgt.p, target.data(), n->out * sizeof(float), hipMemcpyHostToDevice));
-    rc = net_reset_totals(n, nullptr);
-    if (rc) return rc;
-    const uint64_t seed = rng ? rng->seed : 0x5A17ull;
     std::vector<uint32_t> order(n_win);
-    uint64_t draw = 0;
     auto shuffle_epoch = [&](uint32_t ep) -> int {
         if (rng && rng->perm) {
             std::memcpy(order.data(), rng->perm + (size_t)ep * n_win, n_win * sizeof(uint32_t));
@@ -172,69 +154,181 @@ int pretrain_host(Net* n, const float* windows, uint64_t n_win, uint32_t target_
         }
         return SZH_OK;
     };
+    int rc;
     const uint64_t steps_per_epoch = (n_win + bs - 1) / bs;
     // Batches of up to 8 rows (the reference's CLI uses 8) run as one resident kernel per group of
     // epochs: all their shuffles (and injected masks) are uploaded first.
-    const uint64_t group = std::max<uint64_t>(1, std::min<uint64_t>(epochs, (16ull << 20) / n_win));
+    const uint64_t group = std::max<uint64_t>(1, std::min<uint64_t>(n_epochs, (16ull << 20) / n_win));
     if (step_kernel_applies(n, (uint32_t)bs, group * steps_per_epoch)) {
         DevBuf d_perms, d_keeps;
         rc = d_perms.alloc(group * n_win * sizeof(uint32_t));
         if (rc) return rc;
         if (have_keep) { rc = d_keeps.alloc(group * n_win * kFeat); if (rc) return rc; }
         std::vector<uint32_t> orders(group * n_win);
-        for (uint32_t ep0 = 0; ep0 < epochs; ep0 += (uint32_t)group) {
-            const uint32_t ne = (uint32_t)std::min<uint64_t>(group, epochs - ep0);
+        for (uint32_t e0 = 0; e0 < n_epochs; e0 += (uint32_t)group) {
+            const uint32_t ne = (uint32_t)std::min<uint64_t>(group, n_epochs - e0);
             for (uint32_t e = 0; e < ne; ++e) {
-                rc = shuffle_epoch(ep0 + e);
+                rc = shuffle_epoch(ep_first + e0 + e);
                 if (rc) return rc;
                 std::memcpy(orders.data() + (size_t)e * n_win, order.data(), n_win * sizeof(uint32_t));
             }
             SZ_HIP(hipMemcpy(d_perms.p, orders.data(), (size_t)ne * n_win * sizeof(uint32_t), hipMemcpyHostToDevice));
             if (have_keep)
-                SZ_HIP(hipMemcpy(d_keeps.p, rng->keep + (size_t)ep0 * n_win * kFeat, (size_t)ne * n_win * kFeat,
+                SZ_HIP(hipMemcpy(d_keeps.p, rng->keep + (size_t)(ep_first + e0) * n_win * kFeat, (size_t)ne * n_win * kFeat,
                                  hipMemcpyHostToDevice));
-            // the dropout stream is keyed by (seed, epoch * n_win + position, feature)
-            rc = net_pretrain_steps(n, d_win.as<float>(), (uint32_t)n_win, d_perms.as<uint32_t>(),
-                                    have_keep ? d_keeps.as<uint8_t>() : nullptr, dropout, mix64(seed + ep0), d_tgt.as<float>(),
+            // the dropout stream is keyed by (seed of the group, position in the group, feature)
+            rc = net_pretrain_steps(n, d_win, (uint32_t)n_win, d_perms.as<uint32_t>(),
+                                    have_keep ? d_keeps.as<uint8_t>() : nullptr, dropout, mix64(seed + ep_first + e0), d_tgt,
                                     ne, (uint32_t)bs, lr, nullptr);
             if (rc) return rc;
         }
-    } else {
-        for (uint32_t ep = 0; ep < epochs; ++ep) {
-            rc = shuffle_epoch(ep);
+        return SZH_OK;
+    }
+    DevBuf d_perm, d_keep;
+    rc = d_perm.alloc(n_win * sizeof(uint32_t));
+    if (rc) return rc;
+    if (have_keep) { rc = d_keep.alloc(n_win * kFeat); if (rc) return rc; }
+    for (uint32_t ep = ep_first; ep < ep_first + n_epochs; ++ep) {
+        rc = shuffle_epoch(ep);
+        if (rc) return rc;
+        SZ_HIP(hipMemcpyAsync(d_perm.p, order.data(), n_win * sizeof(uint32_t), hipMemcpyHostToDevice, nullptr));
+        if (have_keep)
+            SZ_HIP(hipMemcpyAsync(d_keep.p, rng->keep + (size_t)ep * n_win * kFeat, n_win * kFeat, hipMemcpyHostToDevice,
+                                  nullptr));
+        SZ_HIP(hipStreamSynchronize(nullptr));  // `order` is reused by the next epoch
+        for (uint64_t c0 = 0; c0 < n_win; c0 += bs) {
+            AccumArgs a;
+            a.x_dev = d_win;
+            a.rows = std::min<uint64_t>(bs, n_win - c0);
+            a.perm_dev = d_perm.as<uint32_t>() + c0;
+            a.keep_dev = have_keep ? d_keep.as<uint8_t>() + c0 * kFeat : nullptr;
+            a.dropout = dropout;
+            a.seed = seed;
+            a.row_counter0 = (uint64_t)ep * n_win + c0;
+            a.target_dev = d_tgt;
+            a.skip_zero_rows = true;
+            rc = net_zero_grad(n, nullptr);
             if (rc) return rc;
-            SZ_HIP(hipMemcpyAsync(d_perm.p, order.data(), n_win * sizeof(uint32_t), hipMemcpyHostToDevice, nullptr));
-            if (have_keep)
-                SZ_HIP(hipMemcpyAsync(d_keep.p, rng->keep + (size_t)ep * n_win * kFeat, n_win * kFeat,
-                                      hipMemcpyHostToDevice, nullptr));
-            SZ_HIP(hipStreamSynchronize(nullptr));  // `order` is reused by the next epoch
-            for (uint64_t c0 = 0; c0 < n_win; c0 += bs) {
-                AccumArgs a;
-                a.x_dev = d_win.as<float>();
-                a.rows = std::min<uint64_t>(bs, n_win - c0);
-                a.perm_dev = d_perm.as<uint32_t>() + c0;
-                a.keep_dev = have_keep ? d_keep.as<uint8_t>() + c0 * kFeat : nullptr;
-                a.dropout = dropout;
-                a.seed = seed;
-                a.row_counter0 = (uint64_t)ep * n_win + c0;
-                a.target_dev = d_tgt.as<float>();
-                a.skip_zero_rows = true;
-                rc = net_zero_grad(n, nullptr);
-                if (rc) return rc;
-                rc = net_accumulate(n, a, nullptr);
-                if (rc) return rc;
-                rc = net_apply(n, lr, nullptr);
-                if (rc) return rc;
-            }
+            rc = net_accumulate(n, a, nullptr);
+            if (rc) return rc;
+            rc = net_apply(n, lr, nullptr);
+            if (rc) return rc;
         }
     }
-    rc = net_zero_grad(n, nullptr);  // folds the last step's loss into the running totals
+    return net_zero_grad(n, nullptr);  // folds the last step's loss into the running totals
+}
+
+// one-hot target of width num_classes (lib.rs:592-595), seen through the net's output width
+int upload_target(Net* n, uint32_t target_class, uint32_t num_classes, DevBuf& d_tgt)
+{
+    std::vector<float> target(n->out, 0.0f);
+    if (target_class < num_classes && target_class < n->out) target[target_class] = 1.0f;
+    int rc = d_tgt.alloc(n->out * sizeof(float));
     if (rc) return rc;
+    SZ_HIP(hipMemcpy(d_tgt.p, target.data(), n->out * sizeof(float), hipMemcpyHostToDevice));
+    return SZH_OK;
+}
+
+int read_mean_loss(Net* n, float* mean_loss)
+{
     double loss_sum = 0.0, live = 0.0;
-    rc = net_read_totals(n, nullptr, &loss_sum, &live);
+    int rc = net_read_totals(n, nullptr, &loss_sum, &live);
     if (rc) return rc;
     *mean_loss = live > 0.0 ? (float)(loss_sum / live) : 0.0f;  // lib.rs:623-627
     return SZH_OK;
+}
+
+int pretrain_host(Net* n, const float* windows, uint64_t n_win, uint32_t target_class, uint32_t num_classes,
+                  uint32_t epochs, float lr, float dropout, uint32_t batch_size, const szh_rng* rng, float* mean_loss)
+{
+    *mean_loss = 0.0f;
+    if (n->in != (uint32_t)kFeat) { set_error("pretrain_from_features needs a net with 60 inputs"); return SZH_EINVAL; }
+    if (n_win == 0 || epochs == 0 || n->out == 0) return SZH_OK;
+    if (n_win > 0xffffffffull) { set_error("too many windows"); return SZH_EINVAL; }
+    std::lock_guard<std::mutex> lock(n->mu);
+    const uint64_t bs = batch_size > 0 ? batch_size : 1;  // batch_size.max(1), lib.rs:602
+    DevBuf d_win, d_tgt;
+    int rc = d_win.alloc(n_win * kFeat * sizeof(float));
+    if (rc) return rc;
+    rc = upload_target(n, target_class, num_classes, d_tgt);
+    if (rc) return rc;
+    SZ_HIP(hipMemcpy(d_win.p, windows, n_win * kFeat * sizeof(float), hipMemcpyHostToDevice));
+    rc = net_reset_totals(n, nullptr);
+    if (rc) return rc;
+    uint64_t draw = 0;
+    rc = pretrain_epochs_dev(n, d_win.as<float>(), n_win, d_tgt.as<float>(), 0, epochs, lr, dropout, bs, rng,
+                             rng ? rng->seed : 0x5A17ull, draw);
+    if (rc) return rc;
+    return read_mean_loss(n, mean_loss);
+}
+
+// augment, lib.rs:103-116, on host buffers.  NULL noise: drawn from `seed`.
+int augment_host(const int16_t* pcm, uint64_t n, float gain, float noise_level, uint64_t shift, const float* noise,
+                 uint64_t seed, int16_t* out)
+{
+    if (n == 0) return SZH_OK;
+    DevBuf d_in, d_out, d_noise;
+    int rc = d_in.alloc(n * sizeof(int16_t));
+    if (rc) return rc;
+    rc = d_out.alloc(n * sizeof(int16_t));
+    if (rc) return rc;
+    SZ_HIP(hipMemcpy(d_in.p, pcm, n * sizeof(int16_t), hipMemcpyHostToDevice));
+    if (noise) {
+        rc = d_noise.alloc(n * sizeof(float));
+        if (rc) return rc;
+        SZ_HIP(hipMemcpy(d_noise.p, noise, n * sizeof(float), hipMemcpyHostToDevice));
+    }
+    rc = augment_dev(d_in.as<int16_t>(), n, gain, noise_level, shift, noise ? d_noise.as<float>() : nullptr, seed, 0,
+                     d_out.as<int16_t>(), nullptr);
+    if (rc) return rc;
+    SZ_HIP(hipMemcpy(out, d_out.p, n * sizeof(int16_t), hipMemcpyDeviceToHost));
+    return SZH_OK;
+}
+
+// pretrain_network, lib.rs:348-397: per epoch augment the raw samples, extract, shuffle, train.
+int pretrain_network_host(Net* n, Extractor* e, const int16_t* pcm, uint64_t n_samples, uint32_t target_class,
+                          uint32_t num_classes, uint32_t epochs, float lr, float dropout, uint32_t batch_size,
+                          const szh_aug_draws* aug, const szh_rng* rng, float* mean_loss)
+{
+    *mean_loss = 0.0f;
+    if (n->in != (uint32_t)kFeat) { set_error("pretrain_network needs a net with 60 inputs"); return SZH_EINVAL; }
+    if (n_samples == 0 || epochs == 0 || n->out == 0) return SZH_OK;
+    std::lock_guard<std::mutex> lock(n->mu);
+    const uint64_t bs = batch_size > 0 ? batch_size : 1;
+    const uint64_t seed = rng ? rng->seed : 0x5A17ull;
+    const uint64_t off = 0;
+    Plan* plan = nullptr;
+    int rc = plan_create(e, &off, &n_samples, 1, &plan);
+    if (rc) return rc;
+    struct PlanGuard { Plan* p; ~PlanGuard() { plan_destroy(p); } } guard{plan};
+    const uint64_t n_win = plan->total_windows;
+    DevBuf d_in, d_aug, d_noise, d_feat, d_tgt;
+    if ((rc = d_in.alloc(n_samples * sizeof(int16_t))) || (rc = d_aug.alloc((n_samples + 8) * sizeof(int16_t))) ||
+        (rc = d_feat.alloc((n_win ? n_win : 1) * kFeat * sizeof(float))) || (rc = upload_target(n, target_class, num_classes, d_tgt)))
+        return rc;
+    if (aug && aug->noise) { rc = d_noise.alloc(n_samples * sizeof(float)); if (rc) return rc; }
+    SZ_HIP(hipMemcpy(d_in.p, pcm, n_samples * sizeof(int16_t), hipMemcpyHostToDevice));
+    rc = net_reset_totals(n, nullptr);
+    if (rc) return rc;
+    const uint64_t shift_range = std::min<uint64_t>(n_samples, (uint64_t)kWindow);  // lib.rs:107
+    uint64_t draw = 0;
+    for (uint32_t ep = 0; ep < epochs; ++ep) {
+        // lib.rs:105-107: noise level in [0, 0.005), gain in [0.95, 1.05), shift in [0, min(len, 800))
+        const float level = aug && aug->noise_level ? aug->noise_level[ep] : 0.005f * uniform01(seed, ep, 0xA061);
+        const float gain = aug && aug->gain ? aug->gain[ep] : 0.95f + 0.1f * uniform01(seed, ep, 0xA062);
+        const uint64_t shift = aug && aug->shift ? aug->shift[ep] % shift_range : mix64(seed ^ mix64(0xA063 + ep)) % shift_range;
+        if (aug && aug->noise)
+            SZ_HIP(hipMemcpy(d_noise.p, aug->noise + (size_t)ep * n_samples, n_samples * sizeof(float), hipMemcpyHostToDevice));
+        rc = augment_dev(d_in.as<int16_t>(), n_samples, gain, level, shift, aug && aug->noise ? d_noise.as<float>() : nullptr,
+                         mix64(seed + 0xA064), (uint64_t)ep * n_samples, d_aug.as<int16_t>(), nullptr);
+        if (rc) return rc;
+        if (n_win == 0) continue;
+        rc = plan_run(plan, d_aug.as<int16_t>(), d_feat.as<float>(), nullptr);
+        if (rc) return rc;
+        rc = pretrain_epochs_dev(n, d_feat.as<float>(), n_win, d_tgt.as<float>(), ep, 1, lr, dropout, bs, rng, seed, draw);
+        if (rc) return rc;
+    }
+    return read_mean_loss(n, mean_loss);
 }
 
 // order speakers by vote count, descending, ties by ascending id (stable sort, lib.rs:1403-1410)
@@ -528,6 +622,27 @@ int szh_pretrain_from_features(szh_net* net, const float* windows, uint64_t n_wi
     if (!net || !mean_loss || (n_windows && !windows)) { set_error("null argument"); return SZH_EINVAL; }
     return pretrain_host(reinterpret_cast<Net*>(net), windows, n_windows, target_class, num_classes, epochs, lr,
                          dropout, batch_size, rng, mean_loss);
+    SZ_CATCH
+}
+
+int szh_augment(const int16_t* pcm, uint64_t n_samples, float gain, float noise_level, uint64_t shift, const float* noise,
+                uint64_t seed, int16_t* out)
+{
+    SZ_TRY
+    if (n_samples && (!pcm || !out)) { set_error("null argument"); return SZH_EINVAL; }
+    if (n_samples && shift >= n_samples) { set_error("shift must be below the sample count"); return SZH_EINVAL; }
+    return augment_host(pcm, n_samples, gain, noise_level, shift, noise, seed, out);
+    SZ_CATCH
+}
+
+int szh_pretrain_network(szh_net* net, szh_extractor* ext, const int16_t* pcm, uint64_t n_samples, uint32_t target_class,
+                         uint32_t num_classes, uint32_t epochs, float lr, float dropout, uint32_t batch_size,
+                         const szh_aug_draws* aug, const szh_rng* rng, float* mean_loss)
+{
+    SZ_TRY
+    if (!net || !ext || !mean_loss || (n_samples && !pcm)) { set_error("null argument"); return SZH_EINVAL; }
+    return pretrain_network_host(reinterpret_cast<Net*>(net), reinterpret_cast<Extractor*>(ext), pcm, n_samples, target_class,
+                                 num_classes, epochs, lr, dropout, batch_size, aug, rng, mean_loss);
     SZ_CATCH
 }
 

@@ -11,6 +11,7 @@
 #include "extract_phases.h"
 #include "internal.h"
 #include "prof.h"
+#include "rng.h"
 #include "streamz_hip.h"
 
 namespace sz {
@@ -79,6 +80,21 @@ __global__ __launch_bounds__(kBaseThreads, 2) void mfcc_base_kernel(const int16_
             wave_sync();
         }
     }
+}
+
+// augment, lib.rs:103-116: circular shift, gain, additive noise, clamp, truncating cast.  The
+// three roundings (two products, one sum) are kept separate, as the reference computes them.
+__global__ void augment_kernel(const int16_t* __restrict__ in, uint64_t n, float gain, float level, uint64_t shift,
+                               const float* __restrict__ noise, uint64_t seed, uint64_t counter0, int16_t* __restrict__ out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t idx = i + shift;
+    if (idx >= n) idx -= n;
+    const float nz = noise ? noise[i] : (2.0f * uniform01(seed, counter0 + i, 0xA065ull) - 1.0f) * level;
+    float v = __fadd_rn(__fmul_rn((float)in[idx], gain), __fmul_rn(nz, 32767.0f));
+    v = fminf(fmaxf(v, -32768.0f), 32767.0f);
+    out[i] = (int16_t)(int)v;
 }
 
 constexpr int kFinishThreads = kSegWindows * 4;
@@ -263,6 +279,16 @@ int plan_run(Plan* p, const int16_t* pcm_dev, float* feats_dev, hipStream_t stre
         hipLaunchKernelGGL(finish_kernel, dim3(grid_b), dim3(kFinishThreads), 0, stream, p->d_base, p->d_segs,
                            p->n_segs, feats_dev);
     }
+    SZ_HIP(hipGetLastError());
+    return SZH_OK;
+}
+
+int augment_dev(const int16_t* in, uint64_t n, float gain, float noise_level, uint64_t shift, const float* noise_dev,
+                uint64_t seed, uint64_t counter0, int16_t* out, hipStream_t stream)
+{
+    if (n == 0) return SZH_OK;
+    hipLaunchKernelGGL(augment_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, in, n, gain, noise_level,
+                       shift % n, noise_dev, seed, counter0, out);
     SZ_HIP(hipGetLastError());
     return SZH_OK;
 }

@@ -52,6 +52,10 @@ void extractor_destroy(Extractor* e);
 int plan_create(Extractor* e, const uint64_t* offsets, const uint64_t* lengths, uint32_t n_files, Plan** out);
 void plan_destroy(Plan* p);
 int plan_run(Plan* p, const int16_t* pcm_dev, float* feats_dev, hipStream_t stream);
+// augment (lib.rs:103-116) of n device-resident samples; noise_dev NULL -> counter-based draws
+// keyed by (seed, counter0 + i).
+int augment_dev(const int16_t* in, uint64_t n, float gain, float noise_level, uint64_t shift, const float* noise_dev,
+                uint64_t seed, uint64_t counter0, int16_t* out, hipStream_t stream);
 
 // ---- network -------------------------------------------------------------------------
 struct Workspace {

@@ -261,6 +261,38 @@ inline float pretrain_from_features(SimpleNeuralNet& net, const Features& window
     return loss;
 }
 
+// augment, lib.rs:103-116 (gain, additive noise, circular shift); the draws come from `seed`
+inline std::vector<int16_t> augment(const std::vector<int16_t>& samples, uint64_t seed = 0)
+{
+    std::vector<int16_t> out(samples.size());
+    if (samples.empty()) return out;
+    // the same three draws the reference makes per call (lib.rs:105-107), from a counter-based generator
+    auto u01 = [&](uint64_t k) {
+        uint64_t z = seed + 0x9E3779B97F4A7C15ull * (k + 1);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z ^= z >> 31;
+        return (float)(z >> 40) * (1.0f / 16777216.0f);
+    };
+    const float level = 0.005f * u01(0), gain = 0.95f + 0.1f * u01(1);
+    const uint64_t range = std::min<uint64_t>(samples.size(), 800);
+    const uint64_t shift = (uint64_t)(u01(2) * (float)range) % range;
+    check(szh_augment(samples.data(), samples.size(), gain, level, shift, nullptr, seed, out.data()));
+    return out;
+}
+
+// pretrain_network, lib.rs:348-397
+inline float pretrain_network(SimpleNeuralNet& net, const std::vector<int16_t>& samples, size_t target_class,
+                              size_t num_classes, size_t epochs, float lr, float dropout, size_t batch_size,
+                              const FeatureExtractor& extractor, uint64_t seed = 0)
+{
+    float loss = 0.0f;
+    szh_rng rng{nullptr, nullptr, seed};
+    check(szh_pretrain_network(net.handle(), extractor.handle(), samples.data(), samples.size(), (uint32_t)target_class,
+                               (uint32_t)num_classes, (uint32_t)epochs, lr, dropout, (uint32_t)batch_size, nullptr, &rng, &loss));
+    return loss;
+}
+
 // train_from_feature_map, lib.rs:632-665
 inline float train_from_feature_map(SimpleNeuralNet& net, const std::map<std::string, Features>& feature_map,
                                     const std::vector<std::pair<std::string, size_t>>& files, size_t epochs, float lr,

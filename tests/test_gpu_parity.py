@@ -219,6 +219,68 @@ def test_pretrain_resident_step_kernel_edge_cases(sz, po, dims, batch):
     assert np.isfinite(net.get_flat()).all()
 
 
+def test_augment_is_bit_exact(sz, po):
+    # augment (lib.rs:103-116): integer output, so equality is exact; includes clamping at both
+    # rails, a clip shorter than a window (shift range = len) and the identity setting
+    rng = np.random.default_rng(3)
+    x = rng.integers(-32768, 32768, 5000).astype(np.int16)
+    x[:4] = [32767, -32768, 32767, -32768]
+    for gain, level, shift in [(1.05, 0.005, 799), (0.95, 0.0049, 0), (1.0, 0.0, 123), (1.049, 0.003, 4999)]:
+        noise = rng.uniform(-level, level, x.size).astype(np.float32) if level > 0 else np.zeros(x.size, np.float32)
+        got = sz.augment(x, gain, level, shift, noise=noise)
+        np.testing.assert_array_equal(got, po.augment(x, gain, shift, noise))
+    np.testing.assert_array_equal(sz.augment(x, 1.0, 0.0, 0, noise=np.zeros(x.size, np.float32)), x)
+    short = x[:300]
+    nz = rng.uniform(-0.001, 0.001, 300).astype(np.float32)
+    np.testing.assert_array_equal(sz.augment(short, 1.02, 0.001, 299, noise=nz), po.augment(short, 1.02, 299, nz))
+    # without injected noise the draws stay inside (-level, level): |out - round-trip| is bounded
+    free = sz.augment(x, 1.0, 0.004, 0, seed=9).astype(np.int64)
+    assert np.abs(free - x.astype(np.int64)).max() <= int(0.004 * 32767) + 1 and (free != x).any()
+
+
+def test_pretrain_network_matches_composed_oracle(sz, po, ext, oext):
+    # pretrain_network (lib.rs:348-397): per epoch augment -> extract -> shuffle -> batches of 8.
+    # Every draw is injected on both sides; the oracle side is composed from its augment, extract
+    # and pretrain_from_features.
+    rng = np.random.default_rng(17)
+    n, epochs, C = 44100, 3, 4
+    t = np.arange(n) / 44100.0
+    pcm = np.clip(np.round(8000 * np.sin(2 * np.pi * 180 * t) + 600 * rng.standard_normal(n)), -32768, 32767).astype(np.int16)
+    nw = sz.window_count(n)
+    gain = rng.uniform(0.95, 1.05, epochs).astype(np.float32)
+    level = rng.uniform(0.0005, 0.005, epochs).astype(np.float32)
+    shift = rng.integers(0, 800, epochs).astype(np.uint64)
+    noise = np.stack([rng.uniform(-l, l, n) for l in level]).astype(np.float32)
+    perm = np.stack([rng.permutation(nw) for _ in range(epochs)]).astype(np.uint32)
+    keep = (rng.random((epochs, nw, 60)) >= 0.2).astype(np.uint8)
+    dims = (60, 64, 32, C)
+    onet = po.Net(*dims)
+    params = [rng.uniform(-0.5, 0.5, s).astype(np.float32) for s in onet.shapes()]
+    onet.set_params(params)
+    net = sz.SimpleNeuralNet(*dims, init=params)
+    loss = sz.pretrain_network(net, pcm, 2, C, epochs, 0.01, 0.2, 8, ext, gain=gain, noise_level=level, shift=shift,
+                               noise=noise, perm=perm, keep=keep)
+    tot, cnt = 0.0, 0
+    for ep in range(epochs):
+        aug = po.augment(pcm, float(gain[ep]), int(shift[ep]), noise[ep])
+        feats = oext.extract(aug)
+        assert feats.shape == (nw, 60)
+        live = int((np.where(keep[ep] != 0, feats[perm[ep]], 0.0) != 0).any(axis=1).sum())
+        l = onet.pretrain_from_features(feats, 2, C, 1, 0.01, 0.2, 8, perm=perm[ep:ep + 1], keep=keep[ep:ep + 1])
+        tot += l * live
+        cnt += live
+    assert abs(loss - tot / cnt) < 1e-4 * max(1.0, tot / cnt)
+    for p, q in zip(net.get_params(), onet.get_params()):
+        np.testing.assert_allclose(p, q, atol=1e-4)
+    # no samples / too short for a window: nothing happens, loss 0 (lib.rs:392-396)
+    before = net.get_flat()
+    assert sz.pretrain_network(net, pcm[:500], 2, C, 2, 0.01, 0.2, 8, ext) == 0.0
+    np.testing.assert_array_equal(net.get_flat(), before)
+    # free-running draws: finite result, weights move
+    assert np.isfinite(sz.pretrain_network(net, pcm, 1, C, 2, 0.01, 0.2, 8, ext, seed=5))
+    assert (net.get_flat() != before).any()
+
+
 def test_pretrain_no_windows_returns_zero(sz):
     net = sz.SimpleNeuralNet(60, 8, 4, 2, seed=1)
     before = net.get_flat()
