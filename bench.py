@@ -188,6 +188,9 @@ def main():
     labels = torch.from_numpy(np.repeat(clip_speaker, per_file).astype(np.int32)).to(dev)
     net = sz.SimpleNeuralNet(60, args.hidden1, args.hidden2, args.speakers, seed=42)  # same init on every rank
     grad = torch.as_tensor(_DevView(net.grad_ptr(), net.grad_len()), device=dev)
+    # RCCL reduces a torch-owned staging copy of the 0.67 MB vector (two device copies per step)
+    # rather than library-owned memory it has never seen
+    gstage = torch.empty_like(grad) if world > 1 else None
     stream = torch.cuda.current_stream().cuda_stream
 
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
@@ -201,7 +204,9 @@ def main():
         net.zero_grad_dev(stream)
         net.accumulate_dev(feats.data_ptr(), labels.data_ptr(), n_win, args.dropout, 1000 + k, stream)
         if dist is not None:
-            dist.all_reduce(grad)  # sums gradients, loss and live-row count over ranks
+            gstage.copy_(grad)
+            dist.all_reduce(gstage)  # sums gradients, loss and live-row count over ranks
+            grad.copy_(gstage)
         net.apply_grad_dev(args.lr, stream)
         if record:
             ev[2].record()
@@ -306,7 +311,7 @@ def main():
     }
     if world == 1 and not args.no_extras:
         out["other_figures"] = other_figures(sz, ext, plan, pcm, feats, (60, H1, H2, C), n_win, dev, args.lr, args.dropout)
-    if not args.no_cpu_baseline:
+    if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.speakers, (H1, H2), args.seconds)
     print(json.dumps(out))
     if dist is not None:
