@@ -161,6 +161,8 @@ def main():
     ap.add_argument("--dropout", type=float, default=0.2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to "
+                    "rehearse the multi-rank path on fewer GPUs than ranks)")
     ap.add_argument("--no-extras", action="store_true", help="skip the inference and batch-8 side measurements")
     args = ap.parse_args()
 
@@ -169,8 +171,13 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            local_rank %= torch.cuda.device_count()  # rehearsal: ranks may share a GPU
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(args.backend)
     else:
         dist = None
         torch.cuda.set_device(0)
@@ -190,7 +197,8 @@ def main():
     grad = torch.as_tensor(_DevView(net.grad_ptr(), net.grad_len()), device=dev)
     # RCCL reduces a torch-owned staging copy of the 0.67 MB vector (two device copies per step)
     # rather than library-owned memory it has never seen
-    gstage = torch.empty_like(grad) if world > 1 else None
+    rdev = dev if args.backend == "nccl" else torch.device("cpu")  # gloo rehearsal reduces on the host
+    gstage = torch.empty(grad.shape, dtype=grad.dtype, device=rdev) if world > 1 else None
     stream = torch.cuda.current_stream().cuda_stream
 
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
@@ -235,7 +243,7 @@ def main():
     loss_sum, live = [float(v) for v in grad[-2:].tolist()]
 
     if dist is not None:
-        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tmax = torch.tensor([elapsed], device=rdev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     if rank != 0:
