@@ -128,6 +128,26 @@ def test_cli_sized_net_matches_oracle(sz, po, B, C):
     np.testing.assert_allclose(net.forward(x), onet.forward(x), atol=1e-4)
 
 
+@pytest.mark.parametrize("dims", [(100, 32, 16, 3), (64, 40, 24, 2), (7, 8, 4, 3), (63, 33, 17, 33)])
+def test_other_input_widths_match_oracle(sz, po, dims):
+    # SimpleNeuralNet::new takes any sizes (lib.rs:767); the prepared rows are padded to a tile
+    # ([x | 1 | 0...]), so widths around the 64-column tile boundary are the interesting ones
+    rng = np.random.default_rng(sum(dims))
+    onet = po.Net(*dims)
+    params = [rng.uniform(-0.5, 0.5, s).astype(np.float32) for s in onet.shapes()]
+    onet.set_params(params)
+    net = sz.SimpleNeuralNet(*dims, init=params)
+    for B in (1, 5, 130):
+        x = rng.standard_normal((B, dims[0])).astype(np.float32)
+        target = np.zeros(dims[3], np.float32)
+        target[B % dims[3]] = 1.0
+        np.testing.assert_allclose(net.forward(x), onet.forward(x), atol=1e-4)
+        net.train_batch(x, target, 0.05)
+        onet.train_batch(x, target, 0.05)
+        for p, q in zip(net.get_params(), onet.get_params()):
+            np.testing.assert_allclose(p, q, atol=1e-4)
+
+
 def test_train_equals_train_batch_of_one_and_changes_weights(sz, golden_net):
     g = golden_net
     dims = [int(v) for v in g["tiny_dims"]]
