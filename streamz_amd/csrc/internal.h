@@ -69,7 +69,7 @@ struct Workspace {
     double* stat_slab = nullptr;  // per-workgroup {loss, live rows} partials of the head kernels
     uint64_t slab_floats = 0;
     // regions of `slab` (float offsets): split-K partials of dW1|db1, dW2, dW3|db3 and db2
-    uint64_t sl_w1 = 0, sl_w2 = 0, sl_w3 = 0, sl_b2 = 0;
+    uint64_t sl_w1 = 0, sl_w2 = 0, sl_w3 = 0, sl_b2 = 0, sl_b3 = 0;
 };
 
 struct Net {

@@ -178,6 +178,7 @@ struct HeadArgs {
     const int32_t* labels; // [rows]
     const uint8_t* live;   // [rows]
     float* d2;             // [rows][H2] out
+    float* d3;             // head_wide_kernel only: [rows][C] out, delta3
     float* slab_w3;        // [blocks][H2*C + C]  (dW3 then db3, the layout of the gradient vector)
     float* slab_b2;        // [blocks][H2]
     double* stats;         // [blocks][2] loss and live-row partials
@@ -408,22 +409,24 @@ __device__ __forceinline__ float row16_sum(float x)
 
 #define SZ_MFMA16(a_, b_, c_) __builtin_amdgcn_mfma_f32_16x16x4f32((a_), (b_), (c_), 0, 0, 0)
 
-// w3 in the two MFMA operand layouts head_mfma_kernel multiplies with, as float4 per lane:
-// tab[j*64 + lane] = w3[16j + 4g + 0..3][m], tab[(KB + j)*64 + lane] = w3[16j + m][4g + 0..3],
+// w3 in the two MFMA operand layouts the head kernels multiply with, as float4 per lane, for
+// every block cb of 16 classes:  tab[((2 cb) KB + j) 64 + lane]     = w3[16j + 4g + 0..3][16cb + m],
+//                                tab[((2 cb + 1) KB + j) 64 + lane] = w3[16j + m][16cb + 4g + 0..3],
 // zero beyond column C.
-__global__ void head_tables_kernel(const float* __restrict__ w3, int KB, int C, float* __restrict__ tab)
+__global__ void head_tables_kernel(const float* __restrict__ w3, int KB, int C, int ncb, float* __restrict__ tab)
 {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= KB * 64) return;
-    const int j = e >> 6, mm = e & 15, gg = (e & 63) >> 4;
+    if (e >= ncb * KB * 64) return;
+    const int cb = e / (KB * 64), r = e - cb * KB * 64;
+    const int j = r >> 6, mm = r & 15, gg = (r & 63) >> 4;
     float t[4], u[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        t[q] = mm < C ? w3[(size_t)(16 * j + 4 * gg + q) * C + mm] : 0.0f;
-        u[q] = 4 * gg + q < C ? w3[(size_t)(16 * j + mm) * C + 4 * gg + q] : 0.0f;
+        t[q] = 16 * cb + mm < C ? w3[(size_t)(16 * j + 4 * gg + q) * C + 16 * cb + mm] : 0.0f;
+        u[q] = 16 * cb + 4 * gg + q < C ? w3[(size_t)(16 * j + mm) * C + 16 * cb + 4 * gg + q] : 0.0f;
     }
-    reinterpret_cast<float4*>(tab)[e] = make_float4(t[0], t[1], t[2], t[3]);
-    reinterpret_cast<float4*>(tab)[KB * 64 + e] = make_float4(u[0], u[1], u[2], u[3]);
+    reinterpret_cast<float4*>(tab)[(2 * cb) * KB * 64 + r] = make_float4(t[0], t[1], t[2], t[3]);
+    reinterpret_cast<float4*>(tab)[(2 * cb + 1) * KB * 64 + r] = make_float4(u[0], u[1], u[2], u[3]);
 }
 
 template <int KB>
@@ -653,6 +656,210 @@ __global__ __launch_bounds__(256, 2) void head_mfma_kernel(HeadArgs a)
     }
 }
 
+// The same head for 17..64 classes (NCB blocks of 16): logits, softmax, loss, delta3, delta2, db2
+// and db3 as in head_mfma_kernel, but dW3 = h2^T . delta3 is left to the wide GEMM kernel (a full
+// dW3 would not fit a wave's registers): delta3 is written out, [rows][C].  WAVES waves share the
+// w3 operand images in LDS.
+template <int KB, int NCB, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, 2) void head_wide_kernel(HeadArgs a)
+{
+    constexpr int H2 = KB * 16, THREADS = 64 * WAVES;
+    extern __shared__ __attribute__((aligned(16))) float wtab[];  // 2 NCB KB 64 float4, reused for the sums
+    const int tid = threadIdx.x, lane = tid & 63, m = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int C = a.C;
+    float b3m[NCB], tgt_m[NCB];
+    bool cls[NCB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) {
+        cls[cb] = 16 * cb + m < C;
+        b3m[cb] = cls[cb] ? a.b3[16 * cb + m] : 0.0f;
+        tgt_m[cb] = (a.target && cls[cb]) ? a.target[16 * cb + m] : 0.0f;
+    }
+    f32x4 ident;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) ident[q] = (4 * g + q == m) ? 1.0f : 0.0f;
+    float accb2[KB], accb3[NCB];
+#pragma unroll
+    for (int j = 0; j < KB; ++j) accb2[j] = 0.0f;
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) accb3[cb] = 0.0f;
+    double loss_sum = 0.0;
+    float live_cnt = 0.0f;
+    {
+        const float4* src = reinterpret_cast<const float4*>(a.w3tab);
+        float4* dst = reinterpret_cast<float4*>(wtab);
+        for (int e = tid; e < 2 * NCB * KB * 64; e += THREADS) dst[e] = src[e];
+    }
+    const float4* Wt = reinterpret_cast<const float4*>(wtab);
+    const uint64_t tiles = (a.rows + 15) / 16;
+    const uint64_t t_step = (uint64_t)gridDim.x * WAVES;
+    uint64_t t = (uint64_t)blockIdx.x * WAVES + wave;
+    float4 Ha[KB];
+    {
+        const bool ok0 = t < tiles && t * 16 + m < a.rows;
+        const float* h0 = a.h2 + (ok0 ? t * 16 + m : 0) * H2 + 4 * g;
+#pragma unroll
+        for (int j = 0; j < KB; ++j) Ha[j] = *reinterpret_cast<const float4*>(h0 + 16 * j);
+    }
+    uint32_t lab4 = 0xffffffffu, live4 = 0x01010101u;
+    auto fetch_row_info = [&](uint64_t tile) {
+        const uint64_t last = a.rows - 1;
+        const uint64_t rb = min(tile * 16 + 4 * g, last);
+        if (a.labels) {
+            lab4 = 0;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) lab4 |= ((uint32_t)a.labels[min(rb + v, last)] & 0xffu) << (8 * v);
+        }
+        if (a.live) {
+            live4 = 0;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) live4 |= (uint32_t)a.live[min(rb + v, last)] << (8 * v);
+        }
+    };
+    fetch_row_info(t);
+    __syncthreads();
+    for (; t < tiles; t += t_step) {
+        const uint64_t r0 = t * 16, rm = r0 + m;
+        const bool okm = rm < a.rows;
+        const bool okn = t + t_step < tiles && (t + t_step) * 16 + m < a.rows;
+        const float* hnext = a.h2 + (okn ? (t + t_step) * 16 + m : 0) * H2 + 4 * g;
+        f32x4 L[NCB];
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) L[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < KB; ++j) {
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) {
+                const float4 wb = Wt[((2 * cb) * KB + j) * 64 + lane];
+                L[cb] = SZ_MFMA16(Ha[j].x, wb.x, L[cb]);
+                L[cb] = SZ_MFMA16(Ha[j].y, wb.y, L[cb]);
+                L[cb] = SZ_MFMA16(Ha[j].z, wb.z, L[cb]);
+                L[cb] = SZ_MFMA16(Ha[j].w, wb.w, L[cb]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // softmax over the NCB x 16 classes of a row; loss and delta3 (lib.rs:1022-1028)
+        f32x4 d3[NCB];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const uint64_t rv = r0 + 4 * g + v;
+            const bool okv = rv < a.rows;
+            float x[NCB], mx = -INFINITY;
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) { x[cb] = cls[cb] ? L[cb][v] + b3m[cb] : -INFINITY; mx = fmaxf(mx, x[cb]); }
+            mx = row16_max(mx);
+            float e[NCB], sum = 0.0f;
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) { e[cb] = cls[cb] ? expf(x[cb] - mx) : 0.0f; sum += e[cb]; }
+            sum = row16_sum(sum);
+            const bool alive = okv && ((live4 >> (8 * v)) & 0xffu) != 0;
+            const int lab = (int)((lab4 >> (8 * v)) & 0xffu);
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) {
+                const float o = e[cb] / sum;
+                const float tj = a.labels ? (16 * cb + m == lab ? 1.0f : 0.0f) : tgt_m[cb];
+                float d = 0.0f;
+                if (alive && cls[cb]) {
+                    if (tj != 0.0f) loss_sum -= (double)(tj * logf(fmaxf(o, 1e-12f)));
+                    d = o - tj;
+                }
+                d3[cb][v] = d;
+                accb3[cb] += d;
+                if (okv && cls[cb]) a.d3[rv * C + 16 * cb + m] = d;
+            }
+            if (alive && m == 0) live_cnt += 1.0f;
+        }
+        f32x4 d3t[NCB];  // delta3[row m][class 16cb + 4g + v]
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) {
+            d3t[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int v = 0; v < 4; ++v) d3t[cb] = SZ_MFMA16(d3[cb][v], ident[v], d3t[cb]);
+        }
+#pragma unroll
+        for (int j = 0; j < KB; ++j) {
+            const float4 h = Ha[j];
+            if (j > 0) Ha[j - 1] = *reinterpret_cast<const float4*>(hnext + 16 * (j - 1));
+            f32x4 q = {0.f, 0.f, 0.f, 0.f};   // (delta3 . w3^T)[row m][16j + 4g + v]
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) {
+                const float4 wa = Wt[((2 * cb + 1) * KB + j) * 64 + lane];
+                q = SZ_MFMA16(wa.x, d3t[cb][0], q);
+                q = SZ_MFMA16(wa.y, d3t[cb][1], q);
+                q = SZ_MFMA16(wa.z, d3t[cb][2], q);
+                q = SZ_MFMA16(wa.w, d3t[cb][3], q);
+            }
+            const float4 o = make_float4(q[0] * (1.0f - h.x * h.x), q[1] * (1.0f - h.y * h.y),
+                                         q[2] * (1.0f - h.z * h.z), q[3] * (1.0f - h.w * h.w));
+            f32x4 ot = {0.f, 0.f, 0.f, 0.f};
+            ot = SZ_MFMA16(o.x, ident[0], ot);
+            ot = SZ_MFMA16(o.y, ident[1], ot);
+            ot = SZ_MFMA16(o.z, ident[2], ot);
+            ot = SZ_MFMA16(o.w, ident[3], ot);
+            accb2[j] += (ot[0] + ot[1]) + (ot[2] + ot[3]);
+            if (okm) *reinterpret_cast<float4*>(a.d2 + rm * H2 + 16 * j + 4 * g) = o;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        Ha[KB - 1] = *reinterpret_cast<const float4*>(hnext + 16 * (KB - 1));
+        fetch_row_info(t + t_step);
+    }
+
+    // per-workgroup sums -> slabs (db3 in slab_w3 [blocks][C], db2 in slab_b2 [blocks][H2])
+    float* sb3 = a.slab_w3 + (size_t)blockIdx.x * C;
+    float* sb2 = a.slab_b2 + (size_t)blockIdx.x * H2;
+    const float prev2 = (a.add && tid < H2) ? sb2[tid] : 0.0f;
+    const float prev3 = (a.add && tid < C) ? sb3[tid] : 0.0f;
+    double st_prev[2] = {0.0, 0.0};
+    if (a.add && tid == 0) { st_prev[0] = a.stats[2 * (size_t)blockIdx.x]; st_prev[1] = a.stats[2 * (size_t)blockIdx.x + 1]; }
+#pragma unroll
+    for (int j = 0; j < KB; ++j) {
+        accb2[j] += __shfl_xor(accb2[j], 16);
+        accb2[j] += __shfl_xor(accb2[j], 32);
+    }
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) {
+        accb3[cb] += __shfl_xor(accb3[cb], 16);
+        accb3[cb] += __shfl_xor(accb3[cb], 32);
+    }
+    double live_sum = (double)live_cnt;
+    for (int off = 32; off > 0; off >>= 1) {
+        loss_sum += __shfl_down(loss_sum, off);
+        live_sum += __shfl_down(live_sum, off);
+    }
+    __shared__ double s_stat[2 * WAVES];
+    if (lane == 0) { s_stat[wave] = loss_sum; s_stat[WAVES + wave] = live_sum; }
+    __syncthreads();  // the w3 images are no longer needed; their LDS now holds the per-wave sums
+    float* red = wtab;  // [WAVES][H2 + 16 NCB]
+    constexpr int RW = H2 + 16 * NCB;
+    if (g == 0) {
+#pragma unroll
+        for (int j = 0; j < KB; ++j) red[wave * RW + 16 * j + m] = accb2[j];
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) red[wave * RW + H2 + 16 * cb + m] = accb3[cb];
+    }
+    __syncthreads();
+    if (tid < H2) {
+        float s2 = 0.0f;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) s2 += red[w * RW + tid];
+        sb2[tid] = prev2 + s2;
+    }
+    if (tid < C) {
+        float s3 = 0.0f;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) s3 += red[w * RW + H2 + tid];
+        sb3[tid] = prev3 + s3;
+    }
+    if (tid == 0) {
+        double ls = 0.0, lv = 0.0;
+        for (int w = 0; w < WAVES; ++w) { ls += s_stat[w]; lv += s_stat[WAVES + w]; }
+        double* st = a.stats + 2 * (size_t)blockIdx.x;
+        st[0] = st_prev[0] + ls;
+        st[1] = st_prev[1] + lv;
+    }
+}
+
 // out[c][r] = in[r][c]; 32x32 tiles through LDS
 __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, int rows, int cols,
                                                         float* __restrict__ out)
@@ -800,7 +1007,8 @@ int ensure_workspace(Net* n, uint64_t rows)
     w.sl_w2 = w.sl_w1 + kMaxSplitsW1 * (uint64_t)(n->in + 1) * n->h1;
     w.sl_w3 = w.sl_w2 + kMaxSplits * (uint64_t)n->h1 * n->h2;
     w.sl_b2 = w.sl_w3 + std::max<uint64_t>(kMaxSplits, head_blocks) * len3;
-    w.slab_floats = w.sl_b2 + std::max<uint64_t>(kMaxSplits, head_blocks) * n->h2;
+    w.sl_b3 = w.sl_b2 + std::max<uint64_t>(kMaxSplits, head_blocks) * n->h2;
+    w.slab_floats = w.sl_b3 + head_blocks * 64;
     // prepared rows are padded to a whole tile of columns: [x | 1 | 0...]
     w.ldx = n->in + 1 <= 64 ? 64 : (int)((n->in + 1 + 127) / 128 * 128);
     SZ_HIP(hipMalloc((void**)&w.xd, R * w.ldx * sizeof(float)));
@@ -813,7 +1021,7 @@ int ensure_workspace(Net* n, uint64_t rows)
     SZ_HIP(hipMalloc((void**)&w.live, R));
     SZ_HIP(hipMalloc((void**)&w.mask, ((R + 127) / 128 * 4) * (uint64_t)n->h1 * sizeof(uint32_t)));
     SZ_HIP(hipMalloc((void**)&w.stat_slab, 2 * head_blocks * sizeof(double)));
-    SZ_HIP(hipMalloc((void**)&w.w2t, ((uint64_t)n->h1 * n->h2 + 2 * 64 * 4 * ((n->h2 + 15) / 16)) * sizeof(float)));
+    SZ_HIP(hipMalloc((void**)&w.w2t, ((uint64_t)n->h1 * n->h2 + 8 * 64 * 4 * ((n->h2 + 15) / 16)) * sizeof(float)));
     w.rows = R;
     w.out = n->out;
     return SZH_OK;
@@ -1041,6 +1249,38 @@ int net_read_totals(Net* n, hipStream_t s, double* loss_sum, double* live_rows)
     return SZH_OK;
 }
 
+template <int KB, int NCB, int WAVES>
+int launch_head_wide_one(const HeadArgs& h, int blocks, hipStream_t s)
+{
+    const size_t lds = (size_t)2 * NCB * KB * 64 * sizeof(float4);
+    static bool attr_set = false;
+    if (!attr_set) {
+        SZ_HIP(hipFuncSetAttribute((const void*)head_wide_kernel<KB, NCB, WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((head_wide_kernel<KB, NCB, WAVES>), dim3(blocks), dim3(64 * WAVES), lds, s, h);
+    return SZH_OK;
+}
+
+template <int KB>
+int launch_head_wide_kb(const HeadArgs& h, int ncb, int blocks, hipStream_t s)
+{
+    switch (ncb) {
+    case 2: return launch_head_wide_one<KB, 2, 4>(h, blocks, s);
+    case 3: return launch_head_wide_one<KB, 3, 8>(h, blocks, s);
+    default: return launch_head_wide_one<KB, 4, 8>(h, blocks, s);
+    }
+}
+
+int launch_head_wide(const HeadArgs& h, int kb, int ncb, int blocks, hipStream_t s)
+{
+    switch (kb) {
+    case 16: return launch_head_wide_kb<16>(h, ncb, blocks, s);
+    case 8: return launch_head_wide_kb<8>(h, ncb, blocks, s);
+    default: return launch_head_wide_kb<4>(h, ncb, blocks, s);
+    }
+}
+
 int net_accumulate(Net* n, const AccumArgs& a, hipStream_t s)
 {
     if (a.rows == 0 || n->out == 0) return SZH_OK;
@@ -1062,18 +1302,26 @@ int net_accumulate(Net* n, const AccumArgs& a, hipStream_t s)
     const uint64_t rows0 = std::min<uint64_t>(kChunkRows, a.rows);
     const SplitPlan sp = plan_splits(rows0, (int)kMaxSplits);
     const SplitPlan sp1 = plan_splits(rows0, (int)kMaxSplitsW1);
-    const bool mfma_head = n->out <= 16 && (n->h2 == 64 || n->h2 == 128 || n->h2 == 256);
-    const bool use_head = mfma_head || (n->out <= 32 && n->h2 <= 256 && (n->h2 % 4) == 0);
+    // the output layer: matrix-core head with dW3 in registers (<= 16 classes), matrix-core head
+    // plus a GEMM for dW3 (<= 64 classes), vector head (<= 32 classes, other hidden2), or GEMMs
+    const bool h2_tiles = n->h2 == 64 || n->h2 == 128 || n->h2 == 256;
+    const bool mfma_head = h2_tiles && n->out <= 16;
+    const bool wide_head = h2_tiles && n->out > 16 && n->out <= 64;
+    const bool valu_head = !mfma_head && !wide_head && n->out <= 32 && n->h2 <= 256 && (n->h2 % 4) == 0;
+    const bool use_head = mfma_head || wide_head || valu_head;
+    const int ncb = ((int)n->out + 15) / 16, wide_waves = ncb <= 2 ? 4 : 8;
     const uint64_t len3 = (uint64_t)n->h2 * n->out + n->out;
     int head_blocks = 0, head_tpb = 1;
-    if (mfma_head) {
+    if (mfma_head || wide_head) {
         const int kb = (int)n->h2 / 16;
-        hipLaunchKernelGGL(head_tables_kernel, dim3((kb * 64 + 255) / 256), dim3(256), 0, s, P + n->off_w3(), kb,
-                           (int)n->out, w3tab);
+        hipLaunchKernelGGL(head_tables_kernel, dim3((ncb * kb * 64 + 255) / 256), dim3(256), 0, s, P + n->off_w3(), kb,
+                           (int)n->out, ncb, w3tab);
         SZ_HIP(hipGetLastError());
         const uint64_t wave_tiles = (rows0 + 15) / 16;
-        head_blocks = (int)std::min<uint64_t>(kMHeadBlocks, (wave_tiles + 3) / 4);
-    } else if (use_head) {
+        const int waves = mfma_head ? 4 : wide_waves;
+        head_blocks = (int)std::min<uint64_t>(mfma_head || wide_waves == 4 ? kMHeadBlocks : kMHeadBlocks / 2,
+                                              (wave_tiles + waves - 1) / waves);
+    } else if (valu_head) {
         const int tiles = (int)((rows0 + kHeadRows - 1) / kHeadRows);
         head_blocks = tiles < 2048 ? tiles : 2048;
         head_tpb = (tiles + head_blocks - 1) / head_blocks;
@@ -1105,12 +1353,18 @@ int net_accumulate(Net* n, const AccumArgs& a, hipStream_t s)
             h.add = add ? 1 : 0;
             h.slab_w3 = w.slab + w.sl_w3;
             h.slab_b2 = w.slab + w.sl_b2;
+            h.d3 = w.p;
+            if (wide_head) h.slab_w3 = w.slab + w.sl_b3;  // only db3 comes from this kernel
+            {
             ProfScope prof("head", s);
             if (mfma_head) {
                 // the grid is the same for every chunk, so that each workgroup keeps its slab
                 if (n->h2 == 256) hipLaunchKernelGGL(head_mfma_kernel<16>, dim3(head_blocks), dim3(256), 0, s, h);
                 else if (n->h2 == 128) hipLaunchKernelGGL(head_mfma_kernel<8>, dim3(head_blocks), dim3(256), 0, s, h);
                 else hipLaunchKernelGGL(head_mfma_kernel<4>, dim3(head_blocks), dim3(256), 0, s, h);
+            } else if (wide_head) {
+                rc = launch_head_wide(h, (int)n->h2 / 16, ncb, head_blocks, s);
+                if (rc) return rc;
             } else {
                 const int blocks = (int)(((R + kHeadRows - 1) / kHeadRows + head_tpb - 1) / head_tpb);
                 const int ldh = (int)n->h2 + 4;
@@ -1129,7 +1383,12 @@ int net_accumulate(Net* n, const AccumArgs& a, hipStream_t s)
                 else if (h.Cp == 16) hipLaunchKernelGGL(head_kernel<16>, dim3(blocks), dim3(kHeadThreads), lds, s, h);
                 else hipLaunchKernelGGL(head_kernel<32>, dim3(blocks), dim3(kHeadThreads), lds, s, h);
             }
+            }
             SZ_HIP(hipGetLastError());
+            if (wide_head) {  // dW3 = h2^T . delta3 on the wide GEMM kernel
+                rc = grad_gemm<T_DW3>(w.h2, n->h2, w.p, n->out, n->h2, n->out, R, w.slab + w.sl_w3, sp1, add, false, s);
+                if (rc) return rc;
+            }
         } else {
             rc = forward_logits(n, R, w.p, s);
             if (rc) return rc;
@@ -1165,11 +1424,20 @@ int net_accumulate(Net* n, const AccumArgs& a, hipStream_t s)
         rc = grad_gemm<T_DW1>(w.xd, w.ldx, w.d1, n->h1, n->in + 1, n->h1, R, w.slab + w.sl_w1, sp1, add, false, s, true);
         if (rc) return rc;
     }
-    const int tail_slabs = use_head ? head_blocks : sp.splits;
-    rc = reduce_slabs(w.slab + w.sl_w3, tail_slabs, len3, G + n->off_w3(), s);
-    if (rc) return rc;
-    rc = reduce_slabs(w.slab + w.sl_b2, tail_slabs, n->h2, G + n->off_b2(), s);
-    if (rc) return rc;
+    if (wide_head) {
+        rc = reduce_slabs(w.slab + w.sl_w3, sp1.splits, (uint64_t)n->h2 * n->out, G + n->off_w3(), s);
+        if (rc) return rc;
+        rc = reduce_slabs(w.slab + w.sl_b3, head_blocks, n->out, G + n->off_b3(), s);
+        if (rc) return rc;
+        rc = reduce_slabs(w.slab + w.sl_b2, head_blocks, n->h2, G + n->off_b2(), s);
+        if (rc) return rc;
+    } else {
+        const int tail_slabs = use_head ? head_blocks : sp.splits;
+        rc = reduce_slabs(w.slab + w.sl_w3, tail_slabs, len3, G + n->off_w3(), s);
+        if (rc) return rc;
+        rc = reduce_slabs(w.slab + w.sl_b2, tail_slabs, n->h2, G + n->off_b2(), s);
+        if (rc) return rc;
+    }
     rc = reduce_slabs(w.slab + w.sl_w2, sp.splits, (uint64_t)n->h1 * n->h2, G + n->off_w2(), s);
     if (rc) return rc;
     rc = reduce_slabs(w.slab + w.sl_w1, sp1.splits, (uint64_t)(n->in + 1) * n->h1, G + n->off_w1(), s);

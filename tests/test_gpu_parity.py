@@ -106,7 +106,7 @@ def test_forward_and_train_batch_match_golden(sz, golden_net, name):
 
 
 @pytest.mark.parametrize("B", [1, 8, 1000])
-@pytest.mark.parametrize("C", [16, 3])
+@pytest.mark.parametrize("C", [16, 3, 24, 64])
 def test_cli_sized_net_matches_oracle(sz, po, B, C):
     rng = np.random.default_rng(100 + B + C)
     dims = (60, 512, 256, C)
