@@ -30,7 +30,8 @@ def grad_of(net):
 
 rng = np.random.default_rng(4)
 # MFMA head, VALU head, GEMM output path, MFMA head + dW3 GEMM with 2, 3 and 4 blocks of 16 classes
-for dims in ((60, 512, 256, 16), (60, 64, 32, 5), (60, 96, 40, 40), (60, 64, 128, 17), (60, 128, 64, 40), (60, 512, 256, 64)):
+for dims in ((60, 512, 256, 16), (60, 64, 32, 5), (60, 96, 40, 40), (60, 64, 128, 17), (60, 128, 64, 40), (60, 512, 256, 64),
+             (60, 160, 320, 70)):   # wider than any head kernel: GEMM output path
     onet = po.Net(*dims)
     params = [rng.uniform(-0.5, 0.5, s).astype(np.float32) for s in onet.shapes()]
     onet.set_params(params)
