@@ -182,6 +182,18 @@ int szh_train_from_feature_map(szh_net *net, const float *const *feats, const ui
  * descending (ties keep ascending id); per window the LAST maximum wins. */
 int szh_identify_speaker_list(szh_net *net, szh_extractor *ext, const int16_t *pcm, uint64_t n_samples,
                               float threshold, uint32_t *ids, uint32_t capacity, uint32_t *n_ids);
+/* A recording longer than two tiles is processed tile by tile (8192 windows each unless the
+ * environment variable STREAMZ_TILE_WINDOWS names another size): the tile's launch sequence
+ * is captured once into a HIP graph and replayed, host PCM is staged through two device
+ * buffers so that copies overlap kernels, and the votes stay on the device until the end.
+ * The result does not depend on the tile size.
+ *
+ * szh_identify_speaker_list_dev is the same function (lib.rs:1383-1411) for PCM that already
+ * lies in device memory (16-byte aligned); tile_windows 0 selects the default, and counts
+ * (optional, output_size entries) receives the per-speaker vote counts. */
+int szh_identify_speaker_list_dev(szh_net *net, szh_extractor *ext, const int16_t *pcm_dev, uint64_t n_samples,
+                                  float threshold, uint32_t tile_windows, uint32_t *ids, uint32_t capacity,
+                                  uint32_t *n_ids, uint64_t *counts);
 /* The same vote on feature rows already extracted (loop body of lib.rs:1391-1402).
  * counts (optional, output_size entries) receives the per-speaker vote counts. */
 int szh_identify_from_features(szh_net *net, const float *feats, uint64_t n_windows, float threshold,

@@ -64,6 +64,8 @@ _SIGS = {
                                              C.c_float, C.c_float, C.c_uint32, C.c_uint64, C.POINTER(C.c_float)]),
     "szh_identify_speaker_list": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_float, C.c_void_p,
                                             C.c_uint32, C.POINTER(C.c_uint32)]),
+    "szh_identify_speaker_list_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_float, C.c_uint32,
+                                                C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.c_void_p]),
     "szh_identify_from_features": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_float, C.c_void_p, C.c_uint32,
                                              C.POINTER(C.c_uint32), C.c_void_p]),
     "szh_net_grad_len": (C.c_uint64, [C.c_void_p]),
@@ -426,6 +428,17 @@ def identify_speaker_list(net, sample, threshold, extractor):
     _check(lib().szh_identify_speaker_list(net._h, extractor._h, _p(pcm), pcm.size, threshold, _p(ids), cap,
                                            C.byref(n)))
     return [int(v) for v in ids[:n.value]]
+
+
+def identify_speaker_list_dev(net, pcm_dev_ptr, n_samples, threshold, extractor, tile_windows=0):
+    """identify_speaker_list for int16 PCM at a device address; returns (ids, vote counts)."""
+    cap = max(net.output_size(), 1)
+    ids = np.zeros(cap, np.uint32)
+    counts = np.zeros(cap, np.uint64)
+    n = C.c_uint32()
+    _check(lib().szh_identify_speaker_list_dev(net._h, extractor._h, pcm_dev_ptr, n_samples, threshold, tile_windows,
+                                               _p(ids), cap, C.byref(n), _p(counts)))
+    return [int(v) for v in ids[:n.value]], counts[:net.output_size()].copy()
 
 
 def identify_from_features(net, feats, threshold):

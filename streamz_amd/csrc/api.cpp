@@ -688,6 +688,37 @@ int szh_identify_from_features(szh_net* net, const float* feats, uint64_t n_wind
     SZ_CATCH
 }
 
+// Windows per tile of a long recording; recordings of up to two tiles go through in one piece.
+static uint32_t tile_windows_default()
+{
+    const char* v = std::getenv("STREAMZ_TILE_WINDOWS");
+    const long long t = v ? std::atoll(v) : 0;
+    return t >= 4 && t <= (1ll << 24) ? (uint32_t)t : 8192u;
+}
+
+static int identify_pcm(Net* n, Extractor* e, const int16_t* pcm, bool on_device, uint64_t n_samples, float threshold,
+                        uint32_t tile, uint32_t* ids, uint32_t capacity, uint32_t* n_ids, uint64_t* counts_out)
+{
+    if (n->in != (uint32_t)kFeat) { set_error("identify_speaker_list needs a net with 60 inputs"); return SZH_EINVAL; }
+    if (n->out && !ids) { set_error("null argument"); return SZH_EINVAL; }
+    if (capacity < n->out) { set_error("ids capacity %u < output size %u", capacity, n->out); return SZH_EINVAL; }
+    std::lock_guard<std::mutex> lock(n->mu);
+    std::vector<unsigned long long> counts(n->out, 0);
+    if (n->out > 0 && szh_window_count(n_samples) > 0) {
+        DevBuf d_cnt;
+        int rc = d_cnt.alloc(n->out * sizeof(unsigned long long));
+        if (rc) return rc;
+        SZ_HIP(hipMemset(d_cnt.p, 0, n->out * sizeof(unsigned long long)));
+        rc = identify_tiled(n, e, pcm, on_device, n_samples, threshold, tile, d_cnt.as<unsigned long long>());
+        if (rc) return rc;
+        SZ_HIP(hipMemcpy(counts.data(), d_cnt.p, n->out * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    }
+    *n_ids = order_votes(counts, ids);
+    if (counts_out)
+        for (uint32_t i = 0; i < n->out; ++i) counts_out[i] = counts[i];
+    return SZH_OK;
+}
+
 int szh_identify_speaker_list(szh_net* net, szh_extractor* ext, const int16_t* pcm, uint64_t n_samples,
                               float threshold, uint32_t* ids, uint32_t capacity, uint32_t* n_ids)
 {
@@ -695,26 +726,22 @@ int szh_identify_speaker_list(szh_net* net, szh_extractor* ext, const int16_t* p
     if (!net || !ext || !n_ids || (n_samples && !pcm)) { set_error("null argument"); return SZH_EINVAL; }
     Net* n = reinterpret_cast<Net*>(net);
     Extractor* e = reinterpret_cast<Extractor*>(ext);
-    if (n->in != (uint32_t)kFeat) { set_error("identify_speaker_list needs a net with 60 inputs"); return SZH_EINVAL; }
-    if (n->out && !ids) { set_error("null argument"); return SZH_EINVAL; }
-    std::lock_guard<std::mutex> lock(n->mu);
     const uint64_t nw = szh_window_count(n_samples);
-    DevBuf d_pcm, d_feat;
-    Plan* plan = nullptr;
-    struct PlanGuard { Plan*& p; ~PlanGuard() { plan_destroy(p); } } guard{plan};
-    if (nw) {
-        const uint64_t off = 0;
-        int rc = plan_create(e, &off, &n_samples, 1, &plan);
-        if (rc) return rc;
-        rc = d_pcm.alloc(n_samples * sizeof(int16_t));
-        if (rc) return rc;
-        rc = d_feat.alloc(nw * kFeat * sizeof(float));
-        if (rc) return rc;
-        SZ_HIP(hipMemcpy(d_pcm.p, pcm, n_samples * sizeof(int16_t), hipMemcpyHostToDevice));
-        rc = plan_run(plan, d_pcm.as<int16_t>(), d_feat.as<float>(), nullptr);
-        if (rc) return rc;
-    }
-    return vote_features_dev(n, d_feat.as<float>(), nw, threshold, ids, capacity, n_ids, nullptr);
+    const uint32_t tile = tile_windows_default();
+    // up to two tiles: one copy, one launch sequence
+    const uint32_t one_piece = nw <= 2ull * tile ? (uint32_t)std::max<uint64_t>(nw, 4) : tile;
+    return identify_pcm(n, e, pcm, false, n_samples, threshold, one_piece, ids, capacity, n_ids, nullptr);
+    SZ_CATCH
+}
+
+int szh_identify_speaker_list_dev(szh_net* net, szh_extractor* ext, const int16_t* pcm_dev, uint64_t n_samples,
+                                  float threshold, uint32_t tile_windows, uint32_t* ids, uint32_t capacity,
+                                  uint32_t* n_ids, uint64_t* counts)
+{
+    SZ_TRY
+    if (!net || !ext || !n_ids || (n_samples && !pcm_dev)) { set_error("null argument"); return SZH_EINVAL; }
+    return identify_pcm(reinterpret_cast<Net*>(net), reinterpret_cast<Extractor*>(ext), pcm_dev, true, n_samples,
+                        threshold, tile_windows ? tile_windows : tile_windows_default(), ids, capacity, n_ids, counts);
     SZ_CATCH
 }
 

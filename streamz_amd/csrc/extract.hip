@@ -157,12 +157,18 @@ __global__ __launch_bounds__(kFinishThreads) void finish_kernel(const float* __r
             }
         }
         __syncthreads();
-        float4* dst = reinterpret_cast<float4*>(out + S.win_first * kFeat);
+        float4* dst = reinterpret_cast<float4*>(out + S.out_first * kFeat);
         const float4* src = reinterpret_cast<const float4*>(F);
         const int n4 = (int)S.n_win * (kFeat / 4);
         for (int i = threadIdx.x; i < n4; i += kFinishThreads) dst[i] = src[i];
         __syncthreads();
     }
+}
+
+__global__ void advance_kernel(Segment* segs, uint32_t n_segs, uint64_t samples)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_segs) segs[i].pcm_off += samples;
 }
 
 }  // namespace
@@ -221,6 +227,7 @@ int plan_create(Extractor* e, const uint64_t* offsets, const uint64_t* lengths, 
             Segment s;
             s.pcm_off = offsets[f] + w * kHop;
             s.win_first = p->win_off[f] + w;
+            s.out_first = s.win_first;
             s.file_win_first = p->win_off[f];
             s.n_win = (uint32_t)(nw - w < kSegWindows ? nw - w : kSegWindows);
             s.file_n_win = (uint32_t)nw;
@@ -239,8 +246,65 @@ int plan_create(Extractor* e, const uint64_t* offsets, const uint64_t* lengths, 
             plan_destroy(p);
             return hip_fail(he, "plan allocation");
         }
+        p->d_fin = p->d_segs;
+        p->n_fin = p->n_segs;
     }
     *out = p;
+    return SZH_OK;
+}
+
+int plan_create_tile(Extractor* e, uint64_t pcm_off, uint32_t lead, uint32_t n_out, uint32_t trail, Plan** out)
+{
+    if (pcm_off % 8 != 0) { set_error("tile offset %llu is not a multiple of 8 samples", (unsigned long long)pcm_off); return SZH_EINVAL; }
+    Plan* p = new (std::nothrow) Plan();
+    if (!p) { set_error("out of host memory"); return SZH_ENOMEM; }
+    p->ext = e;
+    const uint32_t nb = lead + n_out + trail;
+    p->win_off = {0, n_out};
+    p->total_windows = n_out;
+    p->pcm_extent = nb ? pcm_off + (uint64_t)(nb - 1) * kHop + kWindow : 0;
+    std::vector<Segment> segs;
+    for (uint32_t w = 0; w < nb; w += kSegWindows) {
+        Segment s{};
+        s.pcm_off = pcm_off + (uint64_t)w * kHop;
+        s.win_first = w;
+        s.n_win = nb - w < kSegWindows ? nb - w : kSegWindows;
+        s.file_n_win = nb;
+        segs.push_back(s);
+    }
+    p->n_segs = (uint32_t)segs.size();
+    for (uint32_t i = 0; i < n_out; i += kSegWindows) {
+        Segment s{};
+        s.win_first = lead + i;
+        s.out_first = i;
+        s.n_win = n_out - i < kSegWindows ? n_out - i : kSegWindows;
+        s.file_n_win = nb;
+        segs.push_back(s);
+    }
+    p->n_fin = (uint32_t)segs.size() - p->n_segs;
+    if (p->n_fin) {
+        hipError_t he = hipMalloc((void**)&p->d_segs, segs.size() * sizeof(Segment));
+        if (he == hipSuccess)
+            he = hipMemcpy(p->d_segs, segs.data(), segs.size() * sizeof(Segment), hipMemcpyHostToDevice);
+        if (he == hipSuccess) he = hipMalloc((void**)&p->d_base, (uint64_t)nb * kMfcc * sizeof(float));
+        if (he != hipSuccess) {
+            plan_destroy(p);
+            return hip_fail(he, "tile plan allocation");
+        }
+        p->d_fin = p->d_segs + p->n_segs;
+    } else {
+        p->n_segs = 0;
+    }
+    *out = p;
+    return SZH_OK;
+}
+
+int plan_advance(Plan* p, uint64_t samples, hipStream_t stream)
+{
+    if (p->n_segs == 0) return SZH_OK;
+    hipLaunchKernelGGL(advance_kernel, dim3((p->n_segs + 63) / 64), dim3(64), 0, stream, p->d_segs, p->n_segs, samples);
+    SZ_HIP(hipGetLastError());
+    p->pcm_extent += samples;
     return SZH_OK;
 }
 
@@ -273,11 +337,11 @@ int plan_run(Plan* p, const int16_t* pcm_dev, float* feats_dev, hipStream_t stre
                            p->d_segs, p->n_segs, p->ext->dev, p->d_base);
     }
     SZ_HIP(hipGetLastError());
-    const uint32_t grid_b = p->n_segs < 256u * 32u ? p->n_segs : 256u * 32u;
+    const uint32_t grid_b = p->n_fin < 256u * 32u ? p->n_fin : 256u * 32u;
     {
         ProfScope prof("finish", stream);
-        hipLaunchKernelGGL(finish_kernel, dim3(grid_b), dim3(kFinishThreads), 0, stream, p->d_base, p->d_segs,
-                           p->n_segs, feats_dev);
+        hipLaunchKernelGGL(finish_kernel, dim3(grid_b), dim3(kFinishThreads), 0, stream, p->d_base, p->d_fin,
+                           p->n_fin, feats_dev);
     }
     SZ_HIP(hipGetLastError());
     return SZH_OK;

@@ -27,6 +27,7 @@ struct Segment {
     uint64_t pcm_off;         // first sample of the segment's first window in the PCM buffer
     uint64_t win_first;       // global index of the segment's first window
     uint64_t file_win_first;  // global index of the owning file's first window
+    uint64_t out_first;       // finish kernel: output row of the segment's first window
     uint32_t n_win;           // windows in this segment (1..kSegWindows)
     uint32_t file_n_win;      // windows in the owning file
 };
@@ -43,8 +44,10 @@ struct Plan {
     uint64_t total_windows = 0;
     uint64_t pcm_extent = 0;        // samples the plan may read: max(offset + length)
     uint32_t n_segs = 0;
-    Segment* d_segs = nullptr;
-    float* d_base = nullptr;        // [total_windows][20] un-normalised MFCCs
+    Segment* d_segs = nullptr;      // windows whose MFCCs are computed
+    uint32_t n_fin = 0;
+    Segment* d_fin = nullptr;       // windows that are finished and written (== d_segs unless a tile)
+    float* d_base = nullptr;        // [base windows][20] un-normalised MFCCs
 };
 
 int extractor_create(Extractor** out);
@@ -52,6 +55,13 @@ void extractor_destroy(Extractor* e);
 int plan_create(Extractor* e, const uint64_t* offsets, const uint64_t* lengths, uint32_t n_files, Plan** out);
 void plan_destroy(Plan* p);
 int plan_run(Plan* p, const int16_t* pcm_dev, float* feats_dev, hipStream_t stream);
+// A tile of a longer recording: MFCCs of lead + n_out + trail consecutive windows are computed
+// (the first one starts at sample pcm_off) and rows lead .. lead + n_out - 1 are finished into
+// feats rows 0 .. n_out - 1.  lead / trail are the neighbours the deltas need (2, or 0 at the
+// recording's own ends, where add_deltas replicates the edge, lib.rs:215-220).
+int plan_create_tile(Extractor* e, uint64_t pcm_off, uint32_t lead, uint32_t n_out, uint32_t trail, Plan** out);
+// moves every window of the plan `samples` further into the PCM buffer (stream-ordered)
+int plan_advance(Plan* p, uint64_t samples, hipStream_t stream);
 // augment (lib.rs:103-116) of n device-resident samples; noise_dev NULL -> counter-based draws
 // keyed by (seed, counter0 + i).
 int augment_dev(const int16_t* in, uint64_t n, float gain, float noise_level, uint64_t shift, const float* noise_dev,
@@ -133,6 +143,12 @@ int net_pretrain_steps(Net* n, const float* d_win, uint32_t n_win, const uint32_
                        float lr, hipStream_t s);
 int net_read_totals(Net* n, hipStream_t s, double* loss_sum, double* live_rows);
 int net_vote_dev(Net* n, const float* x_dev, uint64_t rows, float threshold, unsigned long long* counts_dev, hipStream_t s);
+// sizes the workspace for calls of up to `rows` rows, so that later calls allocate nothing
+int net_reserve_rows(Net* n, uint64_t rows);
+// identify_speaker_list's vote counts for a long recording, tile by tile (stream.cpp).  pcm is a
+// host or a device pointer; counts_dev[out] must be zeroed by the caller.
+int identify_tiled(Net* n, Extractor* e, const int16_t* pcm, bool pcm_on_device, uint64_t n_samples, float threshold,
+                   uint32_t tile_windows, unsigned long long* counts_dev);
 
 // uniform in [-0.5, 0.5) from a counter-based generator; used for weight initialisation
 float init_uniform(uint64_t seed, uint64_t index);

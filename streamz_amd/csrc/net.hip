@@ -1461,6 +1461,8 @@ int net_apply(Net* n, float lr, hipStream_t s)
     return SZH_OK;
 }
 
+int net_reserve_rows(Net* n, uint64_t rows) { return ensure_workspace(n, rows); }
+
 int net_vote_dev(Net* n, const float* x_dev, uint64_t rows, float threshold, unsigned long long* counts_dev,
                  hipStream_t s)
 {

@@ -20,6 +20,8 @@ std::vector<Pair> g_pairs;          // pairs recorded since the last report
 std::vector<Pair> g_free;           // recycled events
 }  // namespace
 
+bool prof_enabled() { return g_on; }
+
 ProfScope::ProfScope(const char* tag, hipStream_t stream)
 {
     if (!g_on) return;

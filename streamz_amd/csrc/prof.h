@@ -4,6 +4,9 @@
 
 namespace sz {
 
+// true while per-kernel timing is switched on
+bool prof_enabled();
+
 // Records an event pair around the launches made while the object lives, when profiling is on.
 class ProfScope {
 public:

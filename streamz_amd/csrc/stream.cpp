@@ -1,0 +1,185 @@
+// identify_speaker_list (lib.rs:1383-1411) over a recording that is too long to treat as one
+// batch: the windows are processed in tiles of a fixed number of windows.  Every tile runs
+// the same launch sequence (MFCCs of the tile plus two neighbour windows each side, deltas
+// and z-score, three layers, softmax, vote), so the sequence is captured once into a HIP
+// graph and replayed; the votes accumulate in device memory and are read once at the end.
+//
+// The deltas of a window need the MFCCs of windows t-2 .. t+2 (add_deltas applied twice,
+// lib.rs:321-322), so a tile recomputes the MFCCs of two windows of each neighbour tile
+// instead of keeping state between tiles.  Edge replication (lib.rs:215-220) happens only in
+// the first and the last tile, which are launched directly.
+#include <algorithm>
+#include <vector>
+
+#include "internal.h"
+#include "prof.h"
+#include "streamz_hip.h"
+
+namespace sz {
+
+namespace {
+
+struct Resources {
+    hipStream_t compute = nullptr, copy = nullptr;
+    hipEvent_t ready[2] = {nullptr, nullptr}, done[2] = {nullptr, nullptr};
+    hipGraph_t graph[2] = {nullptr, nullptr};
+    hipGraphExec_t exec[2] = {nullptr, nullptr};
+    Plan *first = nullptr, *mid = nullptr, *last = nullptr;
+    void* feat = nullptr;
+    void* pcm[2] = {nullptr, nullptr};
+    ~Resources()
+    {
+        if (compute) (void)hipStreamSynchronize(compute);
+        if (copy) (void)hipStreamSynchronize(copy);
+        for (int i = 0; i < 2; ++i) {
+            if (exec[i]) (void)hipGraphExecDestroy(exec[i]);
+            if (graph[i]) (void)hipGraphDestroy(graph[i]);
+            if (ready[i]) (void)hipEventDestroy(ready[i]);
+            if (done[i]) (void)hipEventDestroy(done[i]);
+            if (pcm[i]) (void)hipFree(pcm[i]);
+        }
+        plan_destroy(first);
+        plan_destroy(mid);
+        plan_destroy(last);
+        if (feat) (void)hipFree(feat);
+        if (compute) (void)hipStreamDestroy(compute);
+        if (copy) (void)hipStreamDestroy(copy);
+    }
+};
+
+// samples covered by `windows` consecutive windows
+uint64_t span(uint64_t windows) { return windows ? (windows - 1) * kHop + kWindow : 0; }
+
+int run_tile(Net* n, Plan* plan, const int16_t* pcm_dev, float* feat, uint64_t rows, float threshold,
+             unsigned long long* counts_dev, hipStream_t s)
+{
+    int rc = plan_run(plan, pcm_dev, feat, s);
+    if (rc) return rc;
+    return net_vote_dev(n, feat, rows, threshold, counts_dev, s);
+}
+
+// Captures run_tile (plus `advance` samples of plan movement) on stream s.
+int capture_tile(Resources& r, int slot, Net* n, const int16_t* pcm_dev, uint32_t rows, float threshold,
+                 unsigned long long* counts_dev, uint64_t advance)
+{
+    SZ_HIP(hipStreamBeginCapture(r.compute, hipStreamCaptureModeRelaxed));
+    int rc = run_tile(n, r.mid, pcm_dev, static_cast<float*>(r.feat), rows, threshold, counts_dev, r.compute);
+    if (rc == SZH_OK && advance) rc = plan_advance(r.mid, advance, r.compute);
+    const hipError_t he = hipStreamEndCapture(r.compute, &r.graph[slot]);
+    if (rc) return rc;
+    if (he != hipSuccess) return hip_fail(he, "hipStreamEndCapture");
+    SZ_HIP(hipGraphInstantiate(&r.exec[slot], r.graph[slot], nullptr, nullptr, 0));
+    return SZH_OK;
+}
+
+}  // namespace
+
+int identify_tiled(Net* n, Extractor* e, const int16_t* pcm, bool pcm_on_device, uint64_t n_samples, float threshold,
+                   uint32_t tile_windows, unsigned long long* counts_dev)
+{
+    const uint64_t nw = szh_window_count(n_samples);
+    if (nw == 0 || n->out == 0) return SZH_OK;
+    const uint64_t B = tile_windows;
+    if (B < 4) { set_error("tile_windows must be at least 4"); return SZH_EINVAL; }
+    if (pcm_on_device && ((uintptr_t)pcm & 15) != 0) { set_error("device PCM must be 16-byte aligned"); return SZH_EINVAL; }
+    Resources r;
+    SZ_HIP(hipDeviceSynchronize());  // the caller's work on other streams produced pcm / counts
+    SZ_HIP(hipStreamCreateWithFlags(&r.compute, hipStreamNonBlocking));
+    const bool single = nw <= B + 2;
+    // tile layout: [first: B] [mid: B]* [last: 1 .. B+2]
+    const uint64_t n_mid = single ? 0 : (nw - B - 3) / B;
+    const uint64_t last_first = B + n_mid * B;            // first window of the last tile
+    const uint64_t last_rows = single ? 0 : nw - last_first;
+    const uint64_t feat_rows = single ? nw : std::max<uint64_t>(B, last_rows);
+    int rc = net_reserve_rows(n, feat_rows);
+    if (rc) return rc;
+    SZ_HIP(hipMalloc(&r.feat, feat_rows * kFeat * sizeof(float)));
+    float* feat = static_cast<float*>(r.feat);
+
+    if (pcm_on_device) {
+        if (single) {
+            rc = plan_create_tile(e, 0, 0, (uint32_t)nw, 0, &r.first);
+            if (rc) return rc;
+            rc = run_tile(n, r.first, pcm, feat, nw, threshold, counts_dev, r.compute);
+            if (rc) return rc;
+            SZ_HIP(hipStreamSynchronize(r.compute));
+            return SZH_OK;
+        }
+        rc = plan_create_tile(e, 0, 0, (uint32_t)B, 2, &r.first);
+        if (rc) return rc;
+        rc = run_tile(n, r.first, pcm, feat, B, threshold, counts_dev, r.compute);
+        if (rc) return rc;
+        if (n_mid) {
+            rc = plan_create_tile(e, (B - 2) * kHop, 2, (uint32_t)B, 2, &r.mid);
+            if (rc) return rc;
+            if (prof_enabled()) {
+                // event pairs inside a captured sequence would be replayed, not re-recorded
+                for (uint64_t t = 0; t < n_mid && rc == SZH_OK; ++t) {
+                    rc = run_tile(n, r.mid, pcm, feat, B, threshold, counts_dev, r.compute);
+                    if (rc == SZH_OK) rc = plan_advance(r.mid, B * kHop, r.compute);
+                }
+                if (rc) return rc;
+            } else {
+                rc = capture_tile(r, 0, n, pcm, (uint32_t)B, threshold, counts_dev, B * kHop);
+                if (rc) return rc;
+                for (uint64_t t = 0; t < n_mid; ++t) SZ_HIP(hipGraphLaunch(r.exec[0], r.compute));
+            }
+        }
+        rc = plan_create_tile(e, (last_first - 2) * kHop, 2, (uint32_t)last_rows, 0, &r.last);
+        if (rc) return rc;
+        rc = run_tile(n, r.last, pcm, feat, last_rows, threshold, counts_dev, r.compute);
+        if (rc) return rc;
+        SZ_HIP(hipStreamSynchronize(r.compute));
+        return SZH_OK;
+    }
+
+    // PCM in host memory: tiles are staged through two device buffers; the copy of tile j+1
+    // overlaps the kernels of tile j.
+    const uint64_t buf_windows = single ? nw : std::max<uint64_t>(B + 4, last_rows + 2);
+    SZ_HIP(hipStreamCreateWithFlags(&r.copy, hipStreamNonBlocking));
+    for (int i = 0; i < 2; ++i) {
+        SZ_HIP(hipMalloc(&r.pcm[i], span(buf_windows) * sizeof(int16_t)));
+        SZ_HIP(hipEventCreateWithFlags(&r.ready[i], hipEventDisableTiming));
+        SZ_HIP(hipEventCreateWithFlags(&r.done[i], hipEventDisableTiming));
+    }
+    const uint64_t n_tiles = single ? 1 : n_mid + 2;
+    if (single) {
+        rc = plan_create_tile(e, 0, 0, (uint32_t)nw, 0, &r.first);
+        if (rc) return rc;
+    } else {
+        rc = plan_create_tile(e, 0, 0, (uint32_t)B, 2, &r.first);
+        if (rc == SZH_OK) rc = plan_create_tile(e, 0, 2, (uint32_t)B, 2, &r.mid);
+        if (rc == SZH_OK) rc = plan_create_tile(e, 0, 2, (uint32_t)last_rows, 0, &r.last);
+        if (rc) return rc;
+    }
+    for (uint64_t j = 0; j < n_tiles; ++j) {
+        const int slot = (int)(j & 1);
+        const bool is_first = j == 0, is_last = j + 1 == n_tiles;
+        const uint64_t out_first = j * B;
+        const uint64_t rows = single ? nw : is_last ? last_rows : B;
+        const uint64_t lead = is_first ? 0 : 2, trail = is_last ? 0 : 2;
+        const uint64_t s0 = (out_first - lead) * kHop;
+        const uint64_t len = span(lead + rows + trail);
+        int16_t* buf = static_cast<int16_t*>(r.pcm[slot]);
+        if (j >= 2) SZ_HIP(hipStreamWaitEvent(r.copy, r.done[slot], 0));
+        SZ_HIP(hipMemcpyAsync(buf, pcm + s0, len * sizeof(int16_t), hipMemcpyHostToDevice, r.copy));
+        SZ_HIP(hipEventRecord(r.ready[slot], r.copy));
+        SZ_HIP(hipStreamWaitEvent(r.compute, r.ready[slot], 0));
+        if (is_first || is_last || prof_enabled()) {
+            Plan* plan = is_first ? r.first : is_last ? r.last : r.mid;
+            rc = run_tile(n, plan, buf, feat, rows, threshold, counts_dev, r.compute);
+            if (rc) return rc;
+        } else {
+            if (!r.exec[slot]) {
+                rc = capture_tile(r, slot, n, buf, (uint32_t)B, threshold, counts_dev, 0);
+                if (rc) return rc;
+            }
+            SZ_HIP(hipGraphLaunch(r.exec[slot], r.compute));
+        }
+        SZ_HIP(hipEventRecord(r.done[slot], r.compute));
+    }
+    SZ_HIP(hipStreamSynchronize(r.compute));
+    return SZH_OK;
+}
+
+}  // namespace sz
