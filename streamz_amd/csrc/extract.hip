@@ -8,6 +8,8 @@
 //                     extract_phases.h).  Waves never synchronise with each other.
 //   finish_kernel     deltas with edge replication at file boundaries, concat and per-frame
 //                     z-score (lib.rs:212-228, 321-342); streams 80 B in, 240 B out per window.
+#include <algorithm>
+
 #include "extract_phases.h"
 #include "internal.h"
 #include "prof.h"
@@ -202,13 +204,20 @@ void extractor_destroy(Extractor* e)
     delete e;
 }
 
+// Windows per unit of work of the MFCC kernel (one wave walks a unit 6 windows at a time):
+// small jobs get short units so that every SIMD has a wave, large jobs the full segment.
+static uint32_t base_unit(uint64_t windows)
+{
+    const uint64_t u = (windows / 8192 + kWinPerWave - 1) / kWinPerWave * kWinPerWave;
+    return (uint32_t)std::min<uint64_t>(std::max<uint64_t>(u, kWinPerWave), kSegWindows);
+}
+
 int plan_create(Extractor* e, const uint64_t* offsets, const uint64_t* lengths, uint32_t n_files, Plan** out)
 {
     Plan* p = new (std::nothrow) Plan();
     if (!p) { set_error("out of host memory"); return SZH_ENOMEM; }
     p->ext = e;
     p->win_off.assign((size_t)n_files + 1, 0);
-    std::vector<Segment> segs;
     for (uint32_t f = 0; f < n_files; ++f) {
         if (offsets[f] % 8 != 0) {
             set_error("file %u: offset %llu is not a multiple of 8 samples", f, (unsigned long long)offsets[f]);
@@ -223,20 +232,30 @@ int plan_create(Extractor* e, const uint64_t* offsets, const uint64_t* lengths, 
             delete p;
             return SZH_EINVAL;
         }
-        for (uint64_t w = 0; w < nw; w += kSegWindows) {
-            Segment s;
-            s.pcm_off = offsets[f] + w * kHop;
-            s.win_first = p->win_off[f] + w;
-            s.out_first = s.win_first;
-            s.file_win_first = p->win_off[f];
-            s.n_win = (uint32_t)(nw - w < kSegWindows ? nw - w : kSegWindows);
-            s.file_n_win = (uint32_t)nw;
-            segs.push_back(s);
-        }
     }
     p->total_windows = p->win_off[n_files];
-    if (segs.size() > 0xffffffffull) { set_error("too many segments"); delete p; return SZH_EINVAL; }
-    p->n_segs = (uint32_t)segs.size();
+    const uint32_t unit = base_unit(p->total_windows);
+    std::vector<Segment> segs;
+    for (int pass = 0; pass < 2; ++pass) {  // MFCC units, then the 48-window segments of the finish kernel
+        const uint32_t step = pass == 0 ? unit : kSegWindows;
+        if (pass == 1 && unit == kSegWindows) break;  // both kernels walk the same table
+        for (uint32_t f = 0; f < n_files; ++f) {
+            const uint64_t nw = p->win_off[f + 1] - p->win_off[f];
+            for (uint64_t w = 0; w < nw; w += step) {
+                Segment s{};
+                s.pcm_off = offsets[f] + w * kHop;
+                s.win_first = p->win_off[f] + w;
+                s.out_first = s.win_first;
+                s.file_win_first = p->win_off[f];
+                s.n_win = (uint32_t)(nw - w < step ? nw - w : step);
+                s.file_n_win = (uint32_t)nw;
+                segs.push_back(s);
+            }
+        }
+        if (pass == 0) p->n_segs = (uint32_t)segs.size();
+        if (segs.size() > 0xffffffffull) { set_error("too many segments"); delete p; return SZH_EINVAL; }
+    }
+    p->n_fin = unit == kSegWindows ? p->n_segs : (uint32_t)segs.size() - p->n_segs;
     if (p->n_segs) {
         hipError_t he = hipMalloc((void**)&p->d_segs, segs.size() * sizeof(Segment));
         if (he == hipSuccess)
@@ -246,8 +265,7 @@ int plan_create(Extractor* e, const uint64_t* offsets, const uint64_t* lengths, 
             plan_destroy(p);
             return hip_fail(he, "plan allocation");
         }
-        p->d_fin = p->d_segs;
-        p->n_fin = p->n_segs;
+        p->d_fin = unit == kSegWindows ? p->d_segs : p->d_segs + p->n_segs;
     }
     *out = p;
     return SZH_OK;
@@ -264,11 +282,12 @@ int plan_create_tile(Extractor* e, uint64_t pcm_off, uint32_t lead, uint32_t n_o
     p->total_windows = n_out;
     p->pcm_extent = nb ? pcm_off + (uint64_t)(nb - 1) * kHop + kWindow : 0;
     std::vector<Segment> segs;
-    for (uint32_t w = 0; w < nb; w += kSegWindows) {
+    const uint32_t unit = base_unit(nb);
+    for (uint32_t w = 0; w < nb; w += unit) {
         Segment s{};
         s.pcm_off = pcm_off + (uint64_t)w * kHop;
         s.win_first = w;
-        s.n_win = nb - w < kSegWindows ? nb - w : kSegWindows;
+        s.n_win = nb - w < unit ? nb - w : unit;
         s.file_n_win = nb;
         segs.push_back(s);
     }

@@ -38,7 +38,9 @@ int launch_gemm(GemmArgs g, int splits, hipStream_t s)
     g.a_vec = vec_ok(g.A, g.lda);
     g.b_vec = vec_ok(g.B, g.ldb);
     ProfScope prof(kGemmTagName[TAG], s);
-    if (g.M <= 64) {
+    // 64-row tiles when 128-row tiles would leave compute units without a workgroup
+    const long tiles128 = (long)((g.N + BN - 1) / BN) * ((g.M + BM - 1) / BM) * splits;
+    if (g.M <= 64 || tiles128 < 256) {
         dim3 grid((g.N + BN - 1) / BN, (g.M + 63) / 64, splits);
         hipLaunchKernelGGL((gemm_kernel<AM, BMd, EPI, TAG, 64, kGemmKT, kGemmDB>), grid, dim3(kGemmThreads), 0, s, g);
     } else {
@@ -408,6 +410,110 @@ __device__ __forceinline__ float row16_sum(float x)
 }
 
 #define SZ_MFMA16(a_, b_, c_) __builtin_amdgcn_mfma_f32_16x16x4f32((a_), (b_), (c_), 0, 0, 0)
+
+// ---- inference head: logits, softmax, per-window vote in one pass ------------------------
+// identify_speaker_list's loop body (lib.rs:1391-1401) for up to 64 classes: logits of 16 rows
+// per wave on the 16x16x4 matrix instruction (w3 padded to NCB blocks of 16 classes in LDS, h2
+// read once as 16-byte pieces), softmax over the classes of a row with max subtraction
+// (lib.rs:887-890) across the 16 lanes that hold the row, the last maximum wins, and the
+// thresholded vote goes to a histogram in LDS that is added to counts at the end.
+constexpr int kVoteThreads = 256;
+constexpr size_t kVoteLdsMax = 144 * 1024;
+__host__ __device__ constexpr int vote_ldw(int ncb) { return 16 * ncb + 4; }  // row stride of w3 in LDS
+
+template <int NCB>
+__global__ __launch_bounds__(kVoteThreads) void vote_head_kernel(const float* __restrict__ h2, uint64_t rows, int H2,
+                                                                const float* __restrict__ w3,
+                                                                const float* __restrict__ b3, int C, float threshold,
+                                                                unsigned long long* __restrict__ counts)
+{
+    extern __shared__ __attribute__((aligned(16))) float vlds[];
+    constexpr int LDW = vote_ldw(NCB);
+    float* W = vlds;                                                   // [H2][LDW]
+    unsigned int* hist = reinterpret_cast<unsigned int*>(vlds + (size_t)H2 * LDW);  // [16 * NCB]
+    for (int e = threadIdx.x; e < H2 * 16 * NCB; e += kVoteThreads) {
+        const int k = e / (16 * NCB), c = e - k * (16 * NCB);
+        W[k * LDW + c] = c < C ? w3[(size_t)k * C + c] : 0.0f;
+    }
+    if (threadIdx.x < 16 * NCB) hist[threadIdx.x] = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = lane & 15, q = lane >> 4;
+    float bias[NCB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) bias[cb] = 16 * cb + n < C ? b3[16 * cb + n] : 0.0f;
+    const uint64_t groups = (rows + 15) / 16;
+    for (uint64_t g = (uint64_t)blockIdx.x * (kVoteThreads / 64) + wave; g < groups; g += (uint64_t)gridDim.x * (kVoteThreads / 64)) {
+        const uint64_t row0 = g * 16;
+        // operand A: lane (n, q) holds h2[row0 + n][16 step + 4 q + 0..3]
+        const uint64_t ar = row0 + n < rows ? row0 + n : rows - 1;
+        const float4* src = reinterpret_cast<const float4*>(h2 + ar * H2) + q;
+        f32x4 acc[NCB];
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) acc[cb] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        const int steps = H2 / 16;
+#pragma unroll 4
+        for (int st = 0; st < steps; ++st) {
+            const float4 a = src[4 * st];
+            const float* wr = W + (16 * st + 4 * q) * LDW + n;
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) {
+                acc[cb] = SZ_MFMA16(a.x, wr[16 * cb], acc[cb]);
+                acc[cb] = SZ_MFMA16(a.y, wr[LDW + 16 * cb], acc[cb]);
+                acc[cb] = SZ_MFMA16(a.z, wr[2 * LDW + 16 * cb], acc[cb]);
+                acc[cb] = SZ_MFMA16(a.w, wr[3 * LDW + 16 * cb], acc[cb]);
+            }
+        }
+        // result: register j of lane (n, q) is logit[row0 + 4 q + j][16 cb + n]
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float v[NCB];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) {
+                v[cb] = 16 * cb + n < C ? acc[cb][j] + bias[cb] : -INFINITY;
+                mx = fmaxf(mx, v[cb]);
+            }
+            mx = row16_max(mx);
+            float sum = 0.0f;
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) {
+                v[cb] = 16 * cb + n < C ? expf(v[cb] - mx) : 0.0f;
+                sum += v[cb];
+            }
+            sum = row16_sum(sum);
+            float best = -1.0f, best_c = -1.0f;
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) {
+                const float p = v[cb] / sum;
+                if (16 * cb + n < C && p >= best) { best = p; best_c = (float)(16 * cb + n); }
+            }
+            const float top = row16_max(best);
+            const float win = row16_max(best == top ? best_c : -1.0f);  // the last maximum wins
+            if (n == j && row0 + 4 * q + j < rows && top >= threshold && win >= 0.0f) atomicAdd(&hist[(int)win], 1u);
+        }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < C && hist[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (unsigned long long)hist[threadIdx.x]);
+}
+
+template <int NCB>
+int launch_vote_head(const float* h2, uint64_t rows, int H2, const float* w3, const float* b3, int C, float threshold,
+                     unsigned long long* counts, hipStream_t s)
+{
+    const size_t lds = ((size_t)H2 * vote_ldw(NCB) + 16 * NCB) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        SZ_HIP(hipFuncSetAttribute((const void*)vote_head_kernel<NCB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kVoteLdsMax));
+        attr_set = true;
+    }
+    const uint64_t groups = (rows + 15) / 16;
+    const unsigned blocks = (unsigned)std::min<uint64_t>((groups + 3) / 4, 2048);
+    ProfScope prof("vote_head", s);
+    hipLaunchKernelGGL((vote_head_kernel<NCB>), dim3(blocks), dim3(kVoteThreads), lds, s, h2, rows, H2, w3, b3, C, threshold, counts);
+    SZ_HIP(hipGetLastError());
+    return SZH_OK;
+}
 
 // w3 in the two MFMA operand layouts the head kernels multiply with, as float4 per lane, for
 // every block cb of 16 classes:  tab[((2 cb) KB + j) 64 + lane]     = w3[16j + 4g + 0..3][16cb + m],
@@ -1473,6 +1579,19 @@ int net_vote_dev(Net* n, const float* x_dev, uint64_t rows, float threshold, uns
         const uint64_t R = std::min<uint64_t>(kChunkRows, rows - r0);
         rc = forward_hidden(n, x_dev + r0 * n->in, R, false, s);
         if (rc) return rc;
+        const int ncb = ((int)n->out + 15) / 16;
+        if (ncb <= 4 && n->h2 % 16 == 0 && ((size_t)n->h2 * vote_ldw(ncb) + 16 * ncb) * sizeof(float) <= kVoteLdsMax) {
+            const float* P = n->d_params;
+            const float *w3 = P + n->off_w3(), *b3 = P + n->off_b3();
+            switch (ncb) {
+            case 1: rc = launch_vote_head<1>(n->ws.h2, R, (int)n->h2, w3, b3, (int)n->out, threshold, counts_dev, s); break;
+            case 2: rc = launch_vote_head<2>(n->ws.h2, R, (int)n->h2, w3, b3, (int)n->out, threshold, counts_dev, s); break;
+            case 3: rc = launch_vote_head<3>(n->ws.h2, R, (int)n->h2, w3, b3, (int)n->out, threshold, counts_dev, s); break;
+            default: rc = launch_vote_head<4>(n->ws.h2, R, (int)n->h2, w3, b3, (int)n->out, threshold, counts_dev, s); break;
+            }
+            if (rc) return rc;
+            continue;
+        }
         rc = forward_logits(n, R, n->ws.p, s);
         if (rc) return rc;
         hipLaunchKernelGGL(softmax_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s, n->ws.p, R, (int)n->out,
