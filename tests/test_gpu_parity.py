@@ -128,6 +128,33 @@ def test_cli_sized_net_matches_oracle(sz, po, B, C):
     np.testing.assert_allclose(net.forward(x), onet.forward(x), atol=1e-4)
 
 
+@pytest.mark.parametrize("B", [8, 300])
+def test_wide_net_config(sz, po, B):
+    """hidden 2048 / 2048, 256 speakers (the widest configuration): same f32 kernels, same bar."""
+    rng = np.random.default_rng(2048 + B)
+    dims = (60, 2048, 2048, 256)
+    onet = po.Net(*dims)
+    params = [rng.uniform(-0.5, 0.5, s).astype(np.float32) for s in onet.shapes()]
+    onet.set_params(params)
+    net = sz.SimpleNeuralNet(*dims, init=params)
+    x = rng.standard_normal((B, 60)).astype(np.float32)
+    want = onet.forward(x)
+    np.testing.assert_allclose(net.forward(x), want, atol=1e-4)
+    ids, counts = sz.identify_from_features(net, x, 0.0)
+    # rows whose two best probabilities are closer than the tolerance may vote either way
+    srt = np.sort(want, axis=1)
+    clear = srt[:, -1] - srt[:, -2] > 1e-4
+    want_counts = np.bincount(np.argmax(want[clear], axis=1), minlength=256)
+    assert np.abs(counts.astype(np.int64) - want_counts).sum() <= (~clear).sum() and counts.sum() == B
+    target = np.zeros(256, np.float32)
+    target[200] = 1.0
+    net.train_batch(x, target, 0.01)
+    onet.train_batch(x, target, 0.01)
+    for p, q in zip(net.get_params(), onet.get_params()):
+        np.testing.assert_allclose(p, q, atol=1e-5)
+    np.testing.assert_allclose(net.forward(x), onet.forward(x), atol=1e-4)
+
+
 @pytest.mark.parametrize("dims", [(100, 32, 16, 3), (64, 40, 24, 2), (7, 8, 4, 3), (63, 33, 17, 33)])
 def test_other_input_widths_match_oracle(sz, po, dims):
     # SimpleNeuralNet::new takes any sizes (lib.rs:767); the prepared rows are padded to a tile
