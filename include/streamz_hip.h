@@ -194,6 +194,20 @@ int szh_identify_speaker_list(szh_net *net, szh_extractor *ext, const int16_t *p
 int szh_identify_speaker_list_dev(szh_net *net, szh_extractor *ext, const int16_t *pcm_dev, uint64_t n_samples,
                                   float threshold, uint32_t tile_windows, uint32_t *ids, uint32_t capacity,
                                   uint32_t *n_ids, uint64_t *counts);
+/* identify_speaker, lib.rs:1285-1303: the class whose window probabilities sum highest (the last
+ * maximum wins; 0 for a net without outputs).  sums (optional, output_size entries) receives the
+ * per-class sums.  They are accumulated in f64 on the device and compared as f32; the reference
+ * adds f32 values in window order, so a decision can differ only where its own rounding decides. */
+int szh_identify_speaker(szh_net *net, szh_extractor *ext, const int16_t *pcm, uint64_t n_samples, uint32_t *id,
+                         float *sums);
+/* identify_speaker_with_threshold, lib.rs:1307-1343: *id = the arg-max of the sums if
+ * sum / windows >= threshold, else -1 (None); -1 as well for a net with at most one output or a
+ * sample without a window. */
+int szh_identify_speaker_with_threshold(szh_net *net, szh_extractor *ext, const int16_t *pcm, uint64_t n_samples,
+                                        float threshold, int64_t *id);
+/* identify_speaker_with_threshold_feats, lib.rs:1346-1377: the same on feature rows. */
+int szh_identify_speaker_with_threshold_feats(szh_net *net, const float *feats, uint64_t n_windows, float threshold,
+                                              int64_t *id, float *sums);
 /* The same vote on feature rows already extracted (loop body of lib.rs:1391-1402).
  * counts (optional, output_size entries) receives the per-speaker vote counts. */
 int szh_identify_from_features(szh_net *net, const float *feats, uint64_t n_windows, float threshold,

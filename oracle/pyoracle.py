@@ -67,6 +67,10 @@ def lib():
         L.so_pretrain_from_features.argtypes = [vp, vp, u64, u32, u32, u32, f32, f32, u32, vp, vp]
         L.so_identify_from_features.restype = u32
         L.so_identify_from_features.argtypes = [vp, vp, u64, f32, vp, vp]
+        L.so_identify_speaker_feats.restype = u32
+        L.so_identify_speaker_feats.argtypes = [vp, vp, u64, vp]
+        L.so_identify_speaker_with_threshold_feats.restype = C.c_int64
+        L.so_identify_speaker_with_threshold_feats.argtypes = [vp, vp, u64, f32]
         L.so_identify_speaker_list.restype = u32
         L.so_identify_speaker_list.argtypes = [vp, vp, vp, u64, f32, C.c_int, vp]
         _lib = L
@@ -217,6 +221,19 @@ class Net:
         counts = np.zeros(max(self.out, 1), np.uint64)
         n = lib().so_identify_from_features(self._h, _p(f), f.shape[0], float(threshold), _p(ids), _p(counts))
         return ids[:n].copy(), counts[: self.out].copy()
+
+    def identify_speaker_feats(self, feats):
+        """identify_speaker (lib.rs:1285-1303) on feature rows -> (speaker id, per-class sums)."""
+        f = np.ascontiguousarray(feats, np.float32).reshape(-1, FEAT)
+        sums = np.zeros(max(self.out, 1), np.float32)
+        best = lib().so_identify_speaker_feats(self._h, _p(f), f.shape[0], _p(sums))
+        return int(best), sums[: self.out].copy()
+
+    def identify_speaker_with_threshold_feats(self, feats, threshold):
+        """lib.rs:1346-1377; None when the reference returns None."""
+        f = np.ascontiguousarray(feats, np.float32).reshape(-1, FEAT)
+        r = lib().so_identify_speaker_with_threshold_feats(self._h, _p(f), f.shape[0], float(threshold))
+        return None if r < 0 else int(r)
 
     def identify_speaker_list(self, ext, pcm, threshold, fft_mode=0):
         pcm = np.ascontiguousarray(pcm, np.int16)

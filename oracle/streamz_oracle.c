@@ -586,3 +586,39 @@ uint32_t so_identify_speaker_list(const so_net *net, const so_extractor *e, cons
     free(feats);
     return r;
 }
+
+/* identify_speaker, lib.rs:1285-1303, on feature rows: per-class sums of the window
+ * probabilities (f32, in window order), arg-max with the LAST maximum winning, 0 when the
+ * net has no outputs.  sums_out (optional) receives the sums. */
+uint32_t so_identify_speaker_feats(const so_net *net, const float *feats, uint64_t n_win, float *sums_out)
+{
+    const int C = net->out;
+    float *sums = (float *)calloc(C ? C : 1, sizeof(float));
+    float *out = (float *)malloc(sizeof(float) * (C ? C : 1));
+    for (uint64_t w = 0; w < n_win; ++w) {
+        so_net_forward(net, feats + w * SO_FEAT, 1, out);
+        for (int j = 0; j < C; ++j) sums[j] += out[j];
+    }
+    int best = 0;
+    for (int j = 1; j < C; ++j) if (sums[j] >= sums[best]) best = j;
+    if (sums_out) memcpy(sums_out, sums, sizeof(float) * C);
+    free(sums); free(out);
+    return (uint32_t)best;
+}
+
+/* identify_speaker_with_threshold_feats, lib.rs:1346-1377 (and 1307-1343 after extraction):
+ * -1 (None) for a net with at most one output or no windows; otherwise the arg-max of the
+ * sums if sum / count >= threshold, else -1. */
+int64_t so_identify_speaker_with_threshold_feats(const so_net *net, const float *feats, uint64_t n_win, float threshold)
+{
+    const int C = net->out;
+    if (C <= 1) return -1;
+    float *sums = (float *)calloc(C, sizeof(float));
+    const uint32_t best = so_identify_speaker_feats(net, feats, n_win, sums);
+    float count = 0.0f;
+    for (uint64_t w = 0; w < n_win; ++w) count += 1.0f;
+    int64_t r = -1;
+    if (count != 0.0f && sums[best] / count >= threshold) r = (int64_t)best;
+    free(sums);
+    return r;
+}

@@ -66,6 +66,11 @@ _SIGS = {
                                             C.c_uint32, C.POINTER(C.c_uint32)]),
     "szh_identify_speaker_list_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_float, C.c_uint32,
                                                 C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.c_void_p]),
+    "szh_identify_speaker": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint32), C.c_void_p]),
+    "szh_identify_speaker_with_threshold": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_float,
+                                                      C.POINTER(C.c_int64)]),
+    "szh_identify_speaker_with_threshold_feats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_float,
+                                                            C.POINTER(C.c_int64), C.c_void_p]),
     "szh_identify_from_features": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_float, C.c_void_p, C.c_uint32,
                                              C.POINTER(C.c_uint32), C.c_void_p]),
     "szh_net_grad_len": (C.c_uint64, [C.c_void_p]),
@@ -428,6 +433,33 @@ def identify_speaker_list(net, sample, threshold, extractor):
     _check(lib().szh_identify_speaker_list(net._h, extractor._h, _p(pcm), pcm.size, threshold, _p(ids), cap,
                                            C.byref(n)))
     return [int(v) for v in ids[:n.value]]
+
+
+def identify_speaker(net, sample, extractor, return_sums=False):
+    """identify_speaker (lib.rs:1285-1303)."""
+    pcm = np.ascontiguousarray(sample, np.int16)
+    sums = np.zeros(max(net.output_size(), 1), np.float32)
+    best = C.c_uint32()
+    _check(lib().szh_identify_speaker(net._h, extractor._h, _p(pcm), pcm.size, C.byref(best), _p(sums)))
+    return (best.value, sums[:net.output_size()].copy()) if return_sums else best.value
+
+
+def identify_speaker_with_threshold(net, sample, threshold, extractor):
+    """identify_speaker_with_threshold (lib.rs:1307-1343); None as the reference's None."""
+    pcm = np.ascontiguousarray(sample, np.int16)
+    r = C.c_int64()
+    _check(lib().szh_identify_speaker_with_threshold(net._h, extractor._h, _p(pcm), pcm.size, threshold, C.byref(r)))
+    return None if r.value < 0 else int(r.value)
+
+
+def identify_speaker_with_threshold_feats(net, windows, threshold, return_sums=False):
+    """identify_speaker_with_threshold_feats (lib.rs:1346-1377)."""
+    f = np.ascontiguousarray(windows, np.float32).reshape(-1, FEATURE_SIZE)
+    sums = np.zeros(max(net.output_size(), 1), np.float32)
+    r = C.c_int64()
+    _check(lib().szh_identify_speaker_with_threshold_feats(net._h, _p(f), f.shape[0], threshold, C.byref(r), _p(sums)))
+    got = None if r.value < 0 else int(r.value)
+    return (got, sums[:net.output_size()].copy()) if return_sums else got
 
 
 def identify_speaker_list_dev(net, pcm_dev_ptr, n_samples, threshold, extractor, tile_windows=0):

@@ -354,7 +354,7 @@ int vote_features_dev(Net* n, const float* d_feats, uint64_t n_win, float thresh
         int rc = d_cnt.alloc(n->out * sizeof(unsigned long long));
         if (rc) return rc;
         SZ_HIP(hipMemset(d_cnt.p, 0, n->out * sizeof(unsigned long long)));
-        rc = net_vote_dev(n, d_feats, n_win, threshold, d_cnt.as<unsigned long long>(), nullptr);
+        rc = net_vote_dev(n, d_feats, n_win, threshold, d_cnt.as<unsigned long long>(), nullptr, nullptr);
         if (rc) return rc;
         SZ_HIP(hipStreamSynchronize(nullptr));
         SZ_HIP(hipMemcpy(counts.data(), d_cnt.p, n->out * sizeof(unsigned long long), hipMemcpyDeviceToHost));
@@ -696,27 +696,68 @@ static uint32_t tile_windows_default()
     return t >= 4 && t <= (1ll << 24) ? (uint32_t)t : 8192u;
 }
 
+// Votes and / or probability sums of a recording (host or device PCM), read back to the host.
+static int tally_pcm(Net* n, Extractor* e, const int16_t* pcm, bool on_device, uint64_t n_samples, float threshold,
+                     uint32_t tile, std::vector<unsigned long long>* counts, std::vector<double>* sums)
+{
+    if (n->in != (uint32_t)kFeat) { set_error("identify_speaker* needs a net with 60 inputs"); return SZH_EINVAL; }
+    std::lock_guard<std::mutex> lock(n->mu);
+    if (counts) counts->assign(n->out, 0);
+    if (sums) sums->assign(n->out, 0.0);
+    if (n->out == 0 || szh_window_count(n_samples) == 0) return SZH_OK;
+    DevBuf d_cnt, d_sum;
+    int rc = d_cnt.alloc(n->out * sizeof(unsigned long long));
+    if (rc == SZH_OK) rc = d_sum.alloc(n->out * sizeof(double));
+    if (rc) return rc;
+    SZ_HIP(hipMemset(d_cnt.p, 0, n->out * sizeof(unsigned long long)));
+    SZ_HIP(hipMemset(d_sum.p, 0, n->out * sizeof(double)));
+    rc = identify_tiled(n, e, pcm, on_device, n_samples, threshold, tile, counts ? d_cnt.as<unsigned long long>() : nullptr,
+                        sums ? d_sum.as<double>() : nullptr);
+    if (rc) return rc;
+    if (counts) SZ_HIP(hipMemcpy(counts->data(), d_cnt.p, n->out * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    if (sums) SZ_HIP(hipMemcpy(sums->data(), d_sum.p, n->out * sizeof(double), hipMemcpyDeviceToHost));
+    return SZH_OK;
+}
+
 static int identify_pcm(Net* n, Extractor* e, const int16_t* pcm, bool on_device, uint64_t n_samples, float threshold,
                         uint32_t tile, uint32_t* ids, uint32_t capacity, uint32_t* n_ids, uint64_t* counts_out)
 {
-    if (n->in != (uint32_t)kFeat) { set_error("identify_speaker_list needs a net with 60 inputs"); return SZH_EINVAL; }
     if (n->out && !ids) { set_error("null argument"); return SZH_EINVAL; }
     if (capacity < n->out) { set_error("ids capacity %u < output size %u", capacity, n->out); return SZH_EINVAL; }
-    std::lock_guard<std::mutex> lock(n->mu);
-    std::vector<unsigned long long> counts(n->out, 0);
-    if (n->out > 0 && szh_window_count(n_samples) > 0) {
-        DevBuf d_cnt;
-        int rc = d_cnt.alloc(n->out * sizeof(unsigned long long));
-        if (rc) return rc;
-        SZ_HIP(hipMemset(d_cnt.p, 0, n->out * sizeof(unsigned long long)));
-        rc = identify_tiled(n, e, pcm, on_device, n_samples, threshold, tile, d_cnt.as<unsigned long long>());
-        if (rc) return rc;
-        SZ_HIP(hipMemcpy(counts.data(), d_cnt.p, n->out * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    }
+    std::vector<unsigned long long> counts;
+    const int rc = tally_pcm(n, e, pcm, on_device, n_samples, threshold, tile, &counts, nullptr);
+    if (rc) return rc;
     *n_ids = order_votes(counts, ids);
     if (counts_out)
         for (uint32_t i = 0; i < n->out; ++i) counts_out[i] = counts[i];
     return SZH_OK;
+}
+
+// windows per tile for a host recording of nw windows: up to two tiles go through in one piece
+static uint32_t host_tile(uint64_t nw)
+{
+    const uint32_t tile = tile_windows_default();
+    return nw <= 2ull * tile ? (uint32_t)std::max<uint64_t>(nw, 4) : tile;
+}
+
+// The reference's decision on per-class probability sums (lib.rs:1298-1302, 1332-1342): the
+// sums are compared as f32, the last maximum wins; `count` is the f32 the reference counts
+// windows in, which stops growing at 2^24.
+static uint32_t best_of_sums(const std::vector<double>& sums, float* sums_out)
+{
+    uint32_t best = 0;
+    for (uint32_t j = 0; j < sums.size(); ++j) {
+        if ((float)sums[j] >= (float)sums[best]) best = j;
+        if (sums_out) sums_out[j] = (float)sums[j];
+    }
+    return best;
+}
+static int64_t thresholded(const std::vector<double>& sums, uint64_t n_windows, float threshold, float* sums_out)
+{
+    const uint32_t best = best_of_sums(sums, sums_out);
+    if (sums.size() <= 1 || n_windows == 0) return -1;  // lib.rs:1316-1318, 1329-1331
+    const float count = (float)std::min<uint64_t>(n_windows, 1ull << 24);
+    return (float)sums[best] / count >= threshold ? (int64_t)best : -1;
 }
 
 int szh_identify_speaker_list(szh_net* net, szh_extractor* ext, const int16_t* pcm, uint64_t n_samples,
@@ -724,13 +765,62 @@ int szh_identify_speaker_list(szh_net* net, szh_extractor* ext, const int16_t* p
 {
     SZ_TRY
     if (!net || !ext || !n_ids || (n_samples && !pcm)) { set_error("null argument"); return SZH_EINVAL; }
-    Net* n = reinterpret_cast<Net*>(net);
-    Extractor* e = reinterpret_cast<Extractor*>(ext);
+    return identify_pcm(reinterpret_cast<Net*>(net), reinterpret_cast<Extractor*>(ext), pcm, false, n_samples, threshold,
+                        host_tile(szh_window_count(n_samples)), ids, capacity, n_ids, nullptr);
+    SZ_CATCH
+}
+
+int szh_identify_speaker(szh_net* net, szh_extractor* ext, const int16_t* pcm, uint64_t n_samples, uint32_t* id,
+                         float* sums)
+{
+    SZ_TRY
+    if (!net || !ext || !id || (n_samples && !pcm)) { set_error("null argument"); return SZH_EINVAL; }
+    std::vector<double> s;
+    const int rc = tally_pcm(reinterpret_cast<Net*>(net), reinterpret_cast<Extractor*>(ext), pcm, false, n_samples, 0.0f,
+                             host_tile(szh_window_count(n_samples)), nullptr, &s);
+    if (rc) return rc;
+    *id = best_of_sums(s, sums);
+    return SZH_OK;
+    SZ_CATCH
+}
+
+int szh_identify_speaker_with_threshold(szh_net* net, szh_extractor* ext, const int16_t* pcm, uint64_t n_samples,
+                                        float threshold, int64_t* id)
+{
+    SZ_TRY
+    if (!net || !ext || !id || (n_samples && !pcm)) { set_error("null argument"); return SZH_EINVAL; }
+    std::vector<double> s;
     const uint64_t nw = szh_window_count(n_samples);
-    const uint32_t tile = tile_windows_default();
-    // up to two tiles: one copy, one launch sequence
-    const uint32_t one_piece = nw <= 2ull * tile ? (uint32_t)std::max<uint64_t>(nw, 4) : tile;
-    return identify_pcm(n, e, pcm, false, n_samples, threshold, one_piece, ids, capacity, n_ids, nullptr);
+    const int rc = tally_pcm(reinterpret_cast<Net*>(net), reinterpret_cast<Extractor*>(ext), pcm, false, n_samples, 0.0f,
+                             host_tile(nw), nullptr, &s);
+    if (rc) return rc;
+    *id = thresholded(s, nw, threshold, nullptr);
+    return SZH_OK;
+    SZ_CATCH
+}
+
+int szh_identify_speaker_with_threshold_feats(szh_net* net, const float* feats, uint64_t n_windows, float threshold,
+                                              int64_t* id, float* sums)
+{
+    SZ_TRY
+    if (!net || !id || (n_windows && !feats)) { set_error("null argument"); return SZH_EINVAL; }
+    Net* n = reinterpret_cast<Net*>(net);
+    std::vector<double> s(n->out, 0.0);
+    if (n->out && n_windows) {
+        std::lock_guard<std::mutex> lock(n->mu);
+        DevBuf d_feats, d_sum;
+        int rc = d_feats.alloc(n_windows * n->in * sizeof(float));
+        if (rc == SZH_OK) rc = d_sum.alloc(n->out * sizeof(double));
+        if (rc) return rc;
+        SZ_HIP(hipMemcpy(d_feats.p, feats, n_windows * n->in * sizeof(float), hipMemcpyHostToDevice));
+        SZ_HIP(hipMemset(d_sum.p, 0, n->out * sizeof(double)));
+        rc = net_vote_dev(n, d_feats.as<float>(), n_windows, 0.0f, nullptr, d_sum.as<double>(), nullptr);
+        if (rc) return rc;
+        SZ_HIP(hipStreamSynchronize(nullptr));
+        SZ_HIP(hipMemcpy(s.data(), d_sum.p, n->out * sizeof(double), hipMemcpyDeviceToHost));
+    }
+    *id = thresholded(s, n_windows, threshold, sums);
+    return SZH_OK;
     SZ_CATCH
 }
 
@@ -786,7 +876,7 @@ int szh_net_vote_dev(szh_net* net, const float* feats_dev, uint64_t n, float thr
 {
     SZ_TRY
     if (!net || (n && (!feats_dev || !counts_dev))) { set_error("null argument"); return SZH_EINVAL; }
-    return net_vote_dev(reinterpret_cast<Net*>(net), feats_dev, n, threshold, counts_dev, static_cast<hipStream_t>(stream));
+    return net_vote_dev(reinterpret_cast<Net*>(net), feats_dev, n, threshold, counts_dev, nullptr, static_cast<hipStream_t>(stream));
     SZ_CATCH
 }
 

@@ -142,13 +142,17 @@ int net_pretrain_steps(Net* n, const float* d_win, uint32_t n_win, const uint32_
                        float dropout, uint64_t seed, const float* d_target, uint32_t epochs, uint32_t batch_size,
                        float lr, hipStream_t s);
 int net_read_totals(Net* n, hipStream_t s, double* loss_sum, double* live_rows);
-int net_vote_dev(Net* n, const float* x_dev, uint64_t rows, float threshold, unsigned long long* counts_dev, hipStream_t s);
+// per-window votes (counts_dev[out], optional) and per-class probability sums (psums_dev[out],
+// optional; the sums identify_speaker compares, lib.rs:1290-1297) of `rows` feature rows, added
+// to what the arrays hold
+int net_vote_dev(Net* n, const float* x_dev, uint64_t rows, float threshold, unsigned long long* counts_dev,
+                 double* psums_dev, hipStream_t s);
 // sizes the workspace for calls of up to `rows` rows, so that later calls allocate nothing
 int net_reserve_rows(Net* n, uint64_t rows);
 // identify_speaker_list's vote counts for a long recording, tile by tile (stream.cpp).  pcm is a
-// host or a device pointer; counts_dev[out] must be zeroed by the caller.
+// host or a device pointer; counts_dev[out] / psums_dev[out] (either may be null) are added to.
 int identify_tiled(Net* n, Extractor* e, const int16_t* pcm, bool pcm_on_device, uint64_t n_samples, float threshold,
-                   uint32_t tile_windows, unsigned long long* counts_dev);
+                   uint32_t tile_windows, unsigned long long* counts_dev, double* psums_dev);
 
 // uniform in [-0.5, 0.5) from a counter-based generator; used for weight initialisation
 float init_uniform(uint64_t seed, uint64_t index);

@@ -420,28 +420,34 @@ __device__ __forceinline__ float row16_sum(float x)
 constexpr int kVoteThreads = 256;
 constexpr size_t kVoteLdsMax = 144 * 1024;
 __host__ __device__ constexpr int vote_ldw(int ncb) { return 16 * ncb + 4; }  // row stride of w3 in LDS
+// w3 [H2][ldw] floats, vote histogram [16 ncb] u32, probability sums [16 ncb] f64 (8-byte aligned:
+// the float count before them is even)
+constexpr size_t vote_lds_bytes(int h2, int ncb) { return ((size_t)h2 * vote_ldw(ncb) + 16 * ncb) * sizeof(float) + 16 * ncb * sizeof(double); }
 
 template <int NCB>
 __global__ __launch_bounds__(kVoteThreads) void vote_head_kernel(const float* __restrict__ h2, uint64_t rows, int H2,
                                                                 const float* __restrict__ w3,
                                                                 const float* __restrict__ b3, int C, float threshold,
-                                                                unsigned long long* __restrict__ counts)
+                                                                unsigned long long* __restrict__ counts,
+                                                                double* __restrict__ psums)
 {
     extern __shared__ __attribute__((aligned(16))) float vlds[];
     constexpr int LDW = vote_ldw(NCB);
     float* W = vlds;                                                   // [H2][LDW]
     unsigned int* hist = reinterpret_cast<unsigned int*>(vlds + (size_t)H2 * LDW);  // [16 * NCB]
+    double* dsum = reinterpret_cast<double*>(hist + 16 * NCB);                      // [16 * NCB]
     for (int e = threadIdx.x; e < H2 * 16 * NCB; e += kVoteThreads) {
         const int k = e / (16 * NCB), c = e - k * (16 * NCB);
         W[k * LDW + c] = c < C ? w3[(size_t)k * C + c] : 0.0f;
     }
-    if (threadIdx.x < 16 * NCB) hist[threadIdx.x] = 0;
+    if (threadIdx.x < 16 * NCB) { hist[threadIdx.x] = 0; dsum[threadIdx.x] = 0.0; }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = lane & 15, q = lane >> 4;
     float bias[NCB];
+    double pacc[NCB];  // this lane's share of the per-class probability sums (lib.rs:1292-1296)
 #pragma unroll
-    for (int cb = 0; cb < NCB; ++cb) bias[cb] = 16 * cb + n < C ? b3[16 * cb + n] : 0.0f;
+    for (int cb = 0; cb < NCB; ++cb) { bias[cb] = 16 * cb + n < C ? b3[16 * cb + n] : 0.0f; pacc[cb] = 0.0; }
     const uint64_t groups = (rows + 15) / 16;
     for (uint64_t g = (uint64_t)blockIdx.x * (kVoteThreads / 64) + wave; g < groups; g += (uint64_t)gridDim.x * (kVoteThreads / 64)) {
         const uint64_t row0 = g * 16;
@@ -482,26 +488,48 @@ __global__ __launch_bounds__(kVoteThreads) void vote_head_kernel(const float* __
                 sum += v[cb];
             }
             sum = row16_sum(sum);
+            const bool row_ok = row0 + 4 * q + j < rows;
             float best = -1.0f, best_c = -1.0f;
 #pragma unroll
             for (int cb = 0; cb < NCB; ++cb) {
                 const float p = v[cb] / sum;
                 if (16 * cb + n < C && p >= best) { best = p; best_c = (float)(16 * cb + n); }
+                if (row_ok) pacc[cb] += (double)p;
             }
             const float top = row16_max(best);
             const float win = row16_max(best == top ? best_c : -1.0f);  // the last maximum wins
-            if (n == j && row0 + 4 * q + j < rows && top >= threshold && win >= 0.0f) atomicAdd(&hist[(int)win], 1u);
+            if (n == j && row_ok && top >= threshold && win >= 0.0f) atomicAdd(&hist[(int)win], 1u);
         }
     }
+    if (psums) {
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb)
+            if (16 * cb + n < C) atomicAdd(&dsum[16 * cb + n], pacc[cb]);
+    }
     __syncthreads();
-    if ((int)threadIdx.x < C && hist[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (unsigned long long)hist[threadIdx.x]);
+    if ((int)threadIdx.x < C) {
+        if (counts && hist[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (unsigned long long)hist[threadIdx.x]);
+        if (psums) atomicAdd(&psums[threadIdx.x], dsum[threadIdx.x]);
+    }
+}
+
+// per-class sums of probability rows, for shapes vote_head_kernel does not take
+__global__ void prob_sum_kernel(const float* __restrict__ P, uint64_t rows, int C, double* __restrict__ psums)
+{
+    const uint64_t per = (rows + gridDim.x - 1) / gridDim.x;
+    const uint64_t r0 = blockIdx.x * per, r1 = min(rows, r0 + per);
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        double acc = 0.0;
+        for (uint64_t r = r0; r < r1; ++r) acc += (double)P[r * C + c];
+        if (r1 > r0) atomicAdd(&psums[c], acc);
+    }
 }
 
 template <int NCB>
 int launch_vote_head(const float* h2, uint64_t rows, int H2, const float* w3, const float* b3, int C, float threshold,
-                     unsigned long long* counts, hipStream_t s)
+                     unsigned long long* counts, double* psums, hipStream_t s)
 {
-    const size_t lds = ((size_t)H2 * vote_ldw(NCB) + 16 * NCB) * sizeof(float);
+    const size_t lds = vote_lds_bytes(H2, NCB);
     static bool attr_set = false;
     if (!attr_set) {
         SZ_HIP(hipFuncSetAttribute((const void*)vote_head_kernel<NCB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kVoteLdsMax));
@@ -510,7 +538,7 @@ int launch_vote_head(const float* h2, uint64_t rows, int H2, const float* w3, co
     const uint64_t groups = (rows + 15) / 16;
     const unsigned blocks = (unsigned)std::min<uint64_t>((groups + 3) / 4, 2048);
     ProfScope prof("vote_head", s);
-    hipLaunchKernelGGL((vote_head_kernel<NCB>), dim3(blocks), dim3(kVoteThreads), lds, s, h2, rows, H2, w3, b3, C, threshold, counts);
+    hipLaunchKernelGGL((vote_head_kernel<NCB>), dim3(blocks), dim3(kVoteThreads), lds, s, h2, rows, H2, w3, b3, C, threshold, counts, psums);
     SZ_HIP(hipGetLastError());
     return SZH_OK;
 }
@@ -1570,7 +1598,7 @@ int net_apply(Net* n, float lr, hipStream_t s)
 int net_reserve_rows(Net* n, uint64_t rows) { return ensure_workspace(n, rows); }
 
 int net_vote_dev(Net* n, const float* x_dev, uint64_t rows, float threshold, unsigned long long* counts_dev,
-                 hipStream_t s)
+                 double* psums_dev, hipStream_t s)
 {
     if (rows == 0 || n->out == 0) return SZH_OK;
     int rc = ensure_workspace(n, rows);
@@ -1580,14 +1608,14 @@ int net_vote_dev(Net* n, const float* x_dev, uint64_t rows, float threshold, uns
         rc = forward_hidden(n, x_dev + r0 * n->in, R, false, s);
         if (rc) return rc;
         const int ncb = ((int)n->out + 15) / 16;
-        if (ncb <= 4 && n->h2 % 16 == 0 && ((size_t)n->h2 * vote_ldw(ncb) + 16 * ncb) * sizeof(float) <= kVoteLdsMax) {
+        if (ncb <= 4 && n->h2 % 16 == 0 && vote_lds_bytes((int)n->h2, ncb) <= kVoteLdsMax) {
             const float* P = n->d_params;
             const float *w3 = P + n->off_w3(), *b3 = P + n->off_b3();
             switch (ncb) {
-            case 1: rc = launch_vote_head<1>(n->ws.h2, R, (int)n->h2, w3, b3, (int)n->out, threshold, counts_dev, s); break;
-            case 2: rc = launch_vote_head<2>(n->ws.h2, R, (int)n->h2, w3, b3, (int)n->out, threshold, counts_dev, s); break;
-            case 3: rc = launch_vote_head<3>(n->ws.h2, R, (int)n->h2, w3, b3, (int)n->out, threshold, counts_dev, s); break;
-            default: rc = launch_vote_head<4>(n->ws.h2, R, (int)n->h2, w3, b3, (int)n->out, threshold, counts_dev, s); break;
+            case 1: rc = launch_vote_head<1>(n->ws.h2, R, (int)n->h2, w3, b3, (int)n->out, threshold, counts_dev, psums_dev, s); break;
+            case 2: rc = launch_vote_head<2>(n->ws.h2, R, (int)n->h2, w3, b3, (int)n->out, threshold, counts_dev, psums_dev, s); break;
+            case 3: rc = launch_vote_head<3>(n->ws.h2, R, (int)n->h2, w3, b3, (int)n->out, threshold, counts_dev, psums_dev, s); break;
+            default: rc = launch_vote_head<4>(n->ws.h2, R, (int)n->h2, w3, b3, (int)n->out, threshold, counts_dev, psums_dev, s); break;
             }
             if (rc) return rc;
             continue;
@@ -1598,9 +1626,16 @@ int net_vote_dev(Net* n, const float* x_dev, uint64_t rows, float threshold, uns
                            0, (const float*)nullptr, (const int32_t*)nullptr, (const uint8_t*)nullptr,
                            (double*)nullptr);
         SZ_HIP(hipGetLastError());
-        hipLaunchKernelGGL(vote_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), n->out * sizeof(unsigned int), s,
-                           n->ws.p, R, (int)n->out, threshold, counts_dev);
-        SZ_HIP(hipGetLastError());
+        if (counts_dev) {
+            hipLaunchKernelGGL(vote_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), n->out * sizeof(unsigned int), s,
+                               n->ws.p, R, (int)n->out, threshold, counts_dev);
+            SZ_HIP(hipGetLastError());
+        }
+        if (psums_dev) {
+            hipLaunchKernelGGL(prob_sum_kernel, dim3((unsigned)std::min<uint64_t>((R + 63) / 64, 1024)), dim3(256), 0, s, n->ws.p, R,
+                               (int)n->out, psums_dev);
+            SZ_HIP(hipGetLastError());
+        }
     }
     return SZH_OK;
 }

@@ -50,20 +50,25 @@ struct Resources {
 // samples covered by `windows` consecutive windows
 uint64_t span(uint64_t windows) { return windows ? (windows - 1) * kHop + kWindow : 0; }
 
-int run_tile(Net* n, Plan* plan, const int16_t* pcm_dev, float* feat, uint64_t rows, float threshold,
-             unsigned long long* counts_dev, hipStream_t s)
+struct Tally {
+    float threshold;
+    unsigned long long* counts_dev;  // votes (optional)
+    double* psums_dev;               // probability sums (optional)
+};
+
+int run_tile(Net* n, Plan* plan, const int16_t* pcm_dev, float* feat, uint64_t rows, const Tally& t, hipStream_t s)
 {
     int rc = plan_run(plan, pcm_dev, feat, s);
     if (rc) return rc;
-    return net_vote_dev(n, feat, rows, threshold, counts_dev, s);
+    return net_vote_dev(n, feat, rows, t.threshold, t.counts_dev, t.psums_dev, s);
 }
 
 // Captures run_tile (plus `advance` samples of plan movement) on stream s.
-int capture_tile(Resources& r, int slot, Net* n, const int16_t* pcm_dev, uint32_t rows, float threshold,
-                 unsigned long long* counts_dev, uint64_t advance)
+int capture_tile(Resources& r, int slot, Net* n, const int16_t* pcm_dev, uint32_t rows, const Tally& tally,
+                 uint64_t advance)
 {
     SZ_HIP(hipStreamBeginCapture(r.compute, hipStreamCaptureModeRelaxed));
-    int rc = run_tile(n, r.mid, pcm_dev, static_cast<float*>(r.feat), rows, threshold, counts_dev, r.compute);
+    int rc = run_tile(n, r.mid, pcm_dev, static_cast<float*>(r.feat), rows, tally, r.compute);
     if (rc == SZH_OK && advance) rc = plan_advance(r.mid, advance, r.compute);
     const hipError_t he = hipStreamEndCapture(r.compute, &r.graph[slot]);
     if (rc) return rc;
@@ -75,8 +80,9 @@ int capture_tile(Resources& r, int slot, Net* n, const int16_t* pcm_dev, uint32_
 }  // namespace
 
 int identify_tiled(Net* n, Extractor* e, const int16_t* pcm, bool pcm_on_device, uint64_t n_samples, float threshold,
-                   uint32_t tile_windows, unsigned long long* counts_dev)
+                   uint32_t tile_windows, unsigned long long* counts_dev, double* psums_dev)
 {
+    const Tally tally{threshold, counts_dev, psums_dev};
     const uint64_t nw = szh_window_count(n_samples);
     if (nw == 0 || n->out == 0) return SZH_OK;
     const uint64_t B = tile_windows;
@@ -100,14 +106,14 @@ int identify_tiled(Net* n, Extractor* e, const int16_t* pcm, bool pcm_on_device,
         if (single) {
             rc = plan_create_tile(e, 0, 0, (uint32_t)nw, 0, &r.first);
             if (rc) return rc;
-            rc = run_tile(n, r.first, pcm, feat, nw, threshold, counts_dev, r.compute);
+            rc = run_tile(n, r.first, pcm, feat, nw, tally, r.compute);
             if (rc) return rc;
             SZ_HIP(hipStreamSynchronize(r.compute));
             return SZH_OK;
         }
         rc = plan_create_tile(e, 0, 0, (uint32_t)B, 2, &r.first);
         if (rc) return rc;
-        rc = run_tile(n, r.first, pcm, feat, B, threshold, counts_dev, r.compute);
+        rc = run_tile(n, r.first, pcm, feat, B, tally, r.compute);
         if (rc) return rc;
         if (n_mid) {
             rc = plan_create_tile(e, (B - 2) * kHop, 2, (uint32_t)B, 2, &r.mid);
@@ -115,19 +121,19 @@ int identify_tiled(Net* n, Extractor* e, const int16_t* pcm, bool pcm_on_device,
             if (prof_enabled()) {
                 // event pairs inside a captured sequence would be replayed, not re-recorded
                 for (uint64_t t = 0; t < n_mid && rc == SZH_OK; ++t) {
-                    rc = run_tile(n, r.mid, pcm, feat, B, threshold, counts_dev, r.compute);
+                    rc = run_tile(n, r.mid, pcm, feat, B, tally, r.compute);
                     if (rc == SZH_OK) rc = plan_advance(r.mid, B * kHop, r.compute);
                 }
                 if (rc) return rc;
             } else {
-                rc = capture_tile(r, 0, n, pcm, (uint32_t)B, threshold, counts_dev, B * kHop);
+                rc = capture_tile(r, 0, n, pcm, (uint32_t)B, tally, B * kHop);
                 if (rc) return rc;
                 for (uint64_t t = 0; t < n_mid; ++t) SZ_HIP(hipGraphLaunch(r.exec[0], r.compute));
             }
         }
         rc = plan_create_tile(e, (last_first - 2) * kHop, 2, (uint32_t)last_rows, 0, &r.last);
         if (rc) return rc;
-        rc = run_tile(n, r.last, pcm, feat, last_rows, threshold, counts_dev, r.compute);
+        rc = run_tile(n, r.last, pcm, feat, last_rows, tally, r.compute);
         if (rc) return rc;
         SZ_HIP(hipStreamSynchronize(r.compute));
         return SZH_OK;
@@ -167,11 +173,11 @@ int identify_tiled(Net* n, Extractor* e, const int16_t* pcm, bool pcm_on_device,
         SZ_HIP(hipStreamWaitEvent(r.compute, r.ready[slot], 0));
         if (is_first || is_last || prof_enabled()) {
             Plan* plan = is_first ? r.first : is_last ? r.last : r.mid;
-            rc = run_tile(n, plan, buf, feat, rows, threshold, counts_dev, r.compute);
+            rc = run_tile(n, plan, buf, feat, rows, tally, r.compute);
             if (rc) return rc;
         } else {
             if (!r.exec[slot]) {
-                rc = capture_tile(r, slot, n, buf, (uint32_t)B, threshold, counts_dev, 0);
+                rc = capture_tile(r, slot, n, buf, (uint32_t)B, tally, 0);
                 if (rc) return rc;
             }
             SZ_HIP(hipGraphLaunch(r.exec[slot], r.compute));

@@ -323,6 +323,55 @@ inline std::vector<size_t> identify_speaker_list(const SimpleNeuralNet& net, con
     return std::vector<size_t>(ids.begin(), ids.begin() + n);
 }
 
+// identify_speaker, lib.rs:1285-1303
+inline size_t identify_speaker(const SimpleNeuralNet& net, const std::vector<int16_t>& sample, const FeatureExtractor& ext)
+{
+    uint32_t id = 0;
+    check(szh_identify_speaker(net.handle(), ext.handle(), sample.data(), sample.size(), &id, nullptr));
+    return id;
+}
+
+// identify_speaker_with_threshold, lib.rs:1307-1343 (SIZE_MAX = None)
+inline size_t identify_speaker_with_threshold(const SimpleNeuralNet& net, const std::vector<int16_t>& sample, float threshold,
+                                              const FeatureExtractor& ext)
+{
+    int64_t id = -1;
+    check(szh_identify_speaker_with_threshold(net.handle(), ext.handle(), sample.data(), sample.size(), threshold, &id));
+    return id < 0 ? (size_t)-1 : (size_t)id;
+}
+
+// identify_speaker_with_threshold_feats, lib.rs:1346-1377 (SIZE_MAX = None)
+inline size_t identify_speaker_with_threshold_feats(const SimpleNeuralNet& net, const Features& windows, float threshold)
+{
+    int64_t id = -1;
+    check(szh_identify_speaker_with_threshold_feats(net.handle(), windows.data.data(), windows.len(), threshold, &id, nullptr));
+    return id < 0 ? (size_t)-1 : (size_t)id;
+}
+
+// per-dimension median over the rows of e[n][d], unit norm (lib.rs:1433-1446, 1482-1494)
+inline std::vector<float> median_rows(const std::vector<float>& e, size_t n, size_t d)
+{
+    std::vector<float> emb(d, 0.0f), vals(n);
+    if (n == 0) return emb;
+    for (size_t i = 0; i < d; ++i) {
+        for (size_t w = 0; w < n; ++w) vals[w] = e[w * d + i];
+        std::sort(vals.begin(), vals.end());
+        const size_t mid = n / 2;
+        emb[i] = (n % 2 == 0) ? (vals[mid - 1] + vals[mid]) / 2.0f : vals[mid];
+    }
+    normalize(emb);
+    return emb;
+}
+
+// extract_embedding, lib.rs:1418-1447: median of embed (tanh layer) over the sample's windows
+inline std::vector<float> extract_embedding(const SimpleNeuralNet& net, const std::vector<int16_t>& sample,
+                                            const FeatureExtractor& ext)
+{
+    const Features wins = ext.extract(sample);
+    if (wins.is_empty()) return std::vector<float>(net.embedding_size(), 0.0f);
+    return median_rows(net.embed_rows(wins.data.data(), wins.len()), wins.len(), net.embedding_size());
+}
+
 // extract_embedding_from_features, lib.rs:1450-1471: mean of forward_embedding, unit norm
 inline std::vector<float> extract_embedding_from_features(const SimpleNeuralNet& net, const Features& feats)
 {
@@ -342,18 +391,8 @@ inline std::vector<float> extract_embedding_from_features(const SimpleNeuralNet&
 inline std::vector<float> median_embedding_from_features(const SimpleNeuralNet& net, const Features& feats)
 {
     const size_t d = net.embedding_size(), n = feats.len();
-    std::vector<float> emb(d, 0.0f);
-    if (n == 0) return emb;
-    const std::vector<float> e = net.forward_embedding_rows(feats.data.data(), n);
-    std::vector<float> vals(n);
-    for (size_t i = 0; i < d; ++i) {
-        for (size_t w = 0; w < n; ++w) vals[w] = e[w * d + i];
-        std::sort(vals.begin(), vals.end());
-        const size_t mid = n / 2;
-        emb[i] = (n % 2 == 0) ? (vals[mid - 1] + vals[mid]) / 2.0f : vals[mid];
-    }
-    normalize(emb);
-    return emb;
+    if (n == 0) return std::vector<float>(d, 0.0f);
+    return median_rows(net.forward_embedding_rows(feats.data.data(), n), n, d);
 }
 
 // identify_speaker_from_embedding, lib.rs:1499-1529 (SIZE_MAX = no match)
@@ -368,6 +407,43 @@ inline size_t identify_speaker_from_embedding(const std::vector<float>& emb, con
     }
     const float dyn = speakers.size() < 20 ? threshold * 0.7f : threshold;
     return best_sim > dyn ? best_id : (size_t)-1;
+}
+
+// the acceptance rule shared by identify_speaker_cosine and _feats (lib.rs:1615-1630, 1645-1660);
+// SIZE_MAX = None
+inline size_t best_cosine_match(const std::vector<float>& emb, const std::vector<SimpleNeuralNet::Embedding>& speakers,
+                                float threshold)
+{
+    size_t best_idx = (size_t)-1;
+    float best_val = threshold;
+    for (size_t i = 0; i < speakers.size(); ++i) {
+        const float mean_sim = speakers[i].second.first, std_sim = speakers[i].second.second;
+        const float sim = cosine_similarity(emb, speakers[i].first);
+        if (sim < mean_sim - 2.0f * std_sim) continue;
+        const float adaptive = speakers.size() < 200 ? 0.3f : 1.0f;
+        const float dynamic_threshold = mean_sim + std_sim * adaptive;
+        const bool accepted = sim > 0.35f && (sim > dynamic_threshold || sim > 0.5f);
+        if (accepted && sim > best_val) { best_val = sim; best_idx = i; }
+    }
+    return best_idx;
+}
+
+// identify_speaker_cosine, lib.rs:1604-1631
+inline size_t identify_speaker_cosine(const SimpleNeuralNet& net, const std::vector<SimpleNeuralNet::Embedding>& speakers,
+                                      const std::vector<int16_t>& sample, float threshold, const FeatureExtractor& ext)
+{
+    if (speakers.empty()) return (size_t)-1;
+    return best_cosine_match(extract_embedding(net, sample, ext), speakers, threshold);
+}
+
+// identify_speaker_cosine_feats, lib.rs:1634-1661
+inline size_t identify_speaker_cosine_feats(const SimpleNeuralNet& net, const std::vector<SimpleNeuralNet::Embedding>& speakers,
+                                            const Features& windows, float threshold)
+{
+    if (speakers.empty()) return (size_t)-1;
+    std::vector<float> emb = extract_embedding_from_features(net, windows);
+    normalize(emb);
+    return best_cosine_match(emb, speakers, threshold);
 }
 
 // compute_speaker_embeddings, lib.rs:1555-1599

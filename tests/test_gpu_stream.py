@@ -146,3 +146,55 @@ def test_100h_stream_by_periodicity(sz, nets):
     # every window is counted exactly once when the threshold lets all of them vote
     _, everyone = sz.identify_speaker_list_dev(net, stream.data_ptr(), n_samples, 0.0, ext, tile_windows=8192)
     assert int(everyone.sum()) == nw
+
+
+@pytest.mark.parametrize("classes", [16, 40, 70, 1])
+def test_identify_speaker_and_threshold_siblings(sz, po, classes):
+    """identify_speaker / _with_threshold / _with_threshold_feats (lib.rs:1285-1377): per-class sums
+    of the window probabilities, arg-max, confidence = sum / windows against the threshold."""
+    rng = np.random.default_rng(300 + classes)
+    dims = (60, 128, 64, classes)
+    onet = po.Net(*dims)
+    params = [rng.uniform(-0.5, 0.5, s).astype(np.float32) for s in onet.shapes()]
+    params[4] *= 0.3
+    onet.set_params(params)
+    net = sz.SimpleNeuralNet(*dims, init=params)
+    ext, oext = sz.FeatureExtractor(), po.Extractor()
+    pcm = noise_pcm(rng, 400 * 299 + 800 + 17)
+    feats = oext.extract(pcm, fft_mode=0)
+    nw = feats.shape[0]
+    want_best, want_sums = onet.identify_speaker_feats(feats)
+    best, sums = sz.identify_speaker(net, pcm, ext, return_sums=True)
+    # every window's probabilities are within 1e-4 of the oracle's, so the sums within 1e-4 * windows
+    np.testing.assert_allclose(sums, want_sums, atol=1e-4 * nw)
+    np.testing.assert_allclose(sums, want_sums, atol=5e-3)  # in practice far tighter
+    np.testing.assert_allclose(sums.sum(), nw, rtol=1e-5)
+    if classes > 1:
+        srt = np.sort(want_sums)
+        assert srt[-1] - srt[-2] > 0.05, "pick another seed: the two best sums are too close"
+    assert best == want_best
+    conf = float(want_sums[want_best]) / nw
+    for thr in (conf - 0.01, conf + 0.01, 0.0, 1.1):
+        want = onet.identify_speaker_with_threshold_feats(feats, thr)
+        assert sz.identify_speaker_with_threshold(net, pcm, thr, ext) == want, thr
+        got, fsums = sz.identify_speaker_with_threshold_feats(net, feats, thr, return_sums=True)
+        assert got == want, thr
+        np.testing.assert_allclose(fsums, want_sums, atol=5e-3)
+    if classes == 1:
+        assert onet.identify_speaker_with_threshold_feats(feats, 0.0) is None  # lib.rs:1316-1318
+    # no window: all sums are 0.0 and the last maximum wins (lib.rs:1298-1302); None (lib.rs:1329-1331)
+    assert sz.identify_speaker(net, pcm[:500], ext) == classes - 1 == onet.identify_speaker_feats(feats[:0])[0]
+    assert sz.identify_speaker_with_threshold(net, pcm[:500], 0.0, ext) is None
+    assert sz.identify_speaker_with_threshold_feats(net, feats[:0], 0.0) is None
+    # tile by tile: the same sums up to the order of the f64 additions
+    old = os.environ.get("STREAMZ_TILE_WINDOWS")
+    try:
+        os.environ["STREAMZ_TILE_WINDOWS"] = "64"
+        tbest, tsums = sz.identify_speaker(net, pcm, ext, return_sums=True)
+    finally:
+        if old is None:
+            os.environ.pop("STREAMZ_TILE_WINDOWS", None)
+        else:
+            os.environ["STREAMZ_TILE_WINDOWS"] = old
+    assert tbest == best
+    np.testing.assert_allclose(tsums, sums, rtol=1e-6)
