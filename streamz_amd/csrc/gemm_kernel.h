@@ -2,10 +2,14 @@
 // the tuning harness tools/gemm_bench.hip.
 //
 // C[M][N] = epilogue(sum_k A(m,k) B(k,n)).  Block tile TM x 128 (TM = 128: 4 waves as 2x2 of
-// 64x64; TM = 64: 1x4 of 64x32), K tile KT.  Operand tiles are kept k-major in LDS (row stride
-// 132 floats) so that an MFMA fragment read is 32 consecutive floats per half-wave.  The next K
-// tile is fetched into registers while the current one is multiplied; with DB the LDS tiles are
-// double-buffered and one barrier per K tile suffices.
+// 64x64; TM = 64: 1x4 of 64x32), K tile KT.  One MFMA adds two k values: the one of lanes 0-31
+// and the one of lanes 32-63.  With A row-major in memory (A[m][k]) step s of a K tile pairs
+// k = s with k = s + KT/2, so that the KT/2 values a lane needs from its row of A are contiguous:
+// the A tile stays row-major in LDS (row stride KT + 4 floats; 16-byte stores and loads, no bank
+// conflicts).  Tiles whose rows run along k are kept k-major (row stride 132 floats), a fragment
+// read being 32 consecutive floats per half-wave, and a step pairs k = 2 s with 2 s + 1.  The next K tile is fetched into registers
+// while the current one is multiplied; with DB the LDS tiles are double-buffered and one
+// barrier per K tile suffices.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -88,7 +92,20 @@ __device__ __forceinline__ void fetch_rows(const float* base, int ld, int r0, in
         f[i] = load4(base, r0 + idx / (KT / 4), k0 + 4 * (idx % (KT / 4)), ld, r_max, k_max, vec);
     }
 }
+// the same fragments kept row-major: S[row][k], row stride KT + 4
 template <int TR, int KT>
+__device__ __forceinline__ void stash_rows_rowmajor(float* S, const Frag4 (&f)[TR * KT / 1024])
+{
+#pragma unroll
+    for (int i = 0; i < TR * KT / 1024; ++i) {
+        const int idx = threadIdx.x + kGemmThreads * i;
+        float4 q;
+        q.x = f[i].v[0]; q.y = f[i].v[1]; q.z = f[i].v[2]; q.w = f[i].v[3];
+        *reinterpret_cast<float4*>(S + (idx / (KT / 4)) * (KT + 4) + 4 * (idx % (KT / 4))) = q;
+    }
+}
+// PAIR: as in stash_krows below
+template <int TR, int KT, int PAIR = 0>
 __device__ __forceinline__ void stash_rows(float* S, const Frag4 (&f)[TR * KT / 1024])
 {
 #pragma unroll
@@ -96,7 +113,10 @@ __device__ __forceinline__ void stash_rows(float* S, const Frag4 (&f)[TR * KT / 
         const int idx = threadIdx.x + kGemmThreads * i;
         const int row = idx / (KT / 4), kq = idx % (KT / 4);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) S[(4 * kq + j) * LDR + row] = f[i].v[j];
+        for (int j = 0; j < 4; ++j) {
+            const int k = 4 * kq + j;
+            S[(PAIR ? 2 * (k % (KT / 2)) + k / (KT / 2) : k) * LDR + row] = f[i].v[j];
+        }
     }
 }
 // Tile whose global rows run along k (A[k][m], B[k][n]): 16 k x TR, copied straight.
@@ -116,7 +136,9 @@ __device__ __forceinline__ void fetch_krows(const float* base, int ld, int c0, i
         }
     }
 }
-template <int TR, int KT>
+// PAIR: k row k goes to LDS row 2 (k % (KT/2)) + k / (KT/2), so that rows k and k + KT/2, which
+// one MFMA step multiplies, are neighbours.
+template <int TR, int KT, int PAIR = 0>
 __device__ __forceinline__ void stash_krows(float* S, const Frag4 (&f)[TR * KT / 1024])
 {
 #pragma unroll
@@ -124,7 +146,9 @@ __device__ __forceinline__ void stash_krows(float* S, const Frag4 (&f)[TR * KT /
         const int idx = threadIdx.x + kGemmThreads * i;
         float4 q;
         q.x = f[i].v[0]; q.y = f[i].v[1]; q.z = f[i].v[2]; q.w = f[i].v[3];
-        *reinterpret_cast<float4*>(S + (idx / (TR / 4)) * LDT + 4 * (idx % (TR / 4))) = q;
+        const int k = idx / (TR / 4);
+        const int row = PAIR ? 2 * (k % (KT / 2)) + k / (KT / 2) : k;
+        *reinterpret_cast<float4*>(S + row * LDT + 4 * (idx % (TR / 4))) = q;
     }
 }
 
@@ -159,9 +183,11 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_kernel(GemmArgs g)
     constexpr int WAVES_M = TM / 64, WAVES_N = 4 / WAVES_M;
     constexpr int WN = BN / WAVES_N;  // columns per wave: 64 or 32
     constexpr int TN = WN / 32;       // 32-wide MFMA tiles per wave along N
-    constexpr int LDA = AM == A_ROWS ? LDR : LDT;
+    constexpr int LDA = AM == A_ROWS ? BK + 4 : LDT;  // A_ROWS: row-major tile [TM][BK + 4]
     constexpr int LDB = BMd == B_ROWS ? LDR : LDT;
-    __shared__ __attribute__((aligned(16))) float As_[(DB ? 2 : 1) * BK * LDT];
+    constexpr int HS = BK / 2;                        // MFMA steps per K tile
+    constexpr int A_TILE = AM == A_ROWS ? TM * LDA : BK * LDT;
+    __shared__ __attribute__((aligned(16))) float As_[(DB ? 2 : 1) * A_TILE];
     __shared__ __attribute__((aligned(16))) float Bs_[(DB ? 2 : 1) * BK * LDT];
     // Workgroups are handed to the 8 XCDs round-robin in launch order.  Tiles are renumbered so
     // that each XCD works on one contiguous run of them (column tiles of a row tile, then row
@@ -231,10 +257,10 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_kernel(GemmArgs g)
         }
     };
     auto stash = [&](int buf) {
-        float* As = As_ + buf * BK * LDT;
+        float* As = As_ + buf * A_TILE;
         float* Bs = Bs_ + buf * BK * LDT;
-        if (AM == A_ROWS) stash_rows<TM, BK>(As, fa); else stash_krows<TM, BK>(As, fa);
-        if (BMd == B_ROWS) stash_rows<BN, BK>(Bs, fb); else stash_krows<BN, BK>(Bs, fb);
+        if (AM == A_ROWS) stash_rows_rowmajor<TM, BK>(As, fa); else stash_krows<TM, BK>(As, fa);
+        if (BMd == B_ROWS) stash_rows<BN, BK, AM == A_ROWS>(Bs, fb); else stash_krows<BN, BK, AM == A_ROWS>(Bs, fb);
     };
     if (k_begin < k_end) fetch(k_begin);
     if (DB && k_begin < k_end) { stash(0); __syncthreads(); }
@@ -246,27 +272,59 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_kernel(GemmArgs g)
             __syncthreads();
         }
         if (k0 + BK < k_end) fetch(k0 + BK);
-        const float* As = As_ + buf * BK * LDT;
+        const float* As = As_ + buf * A_TILE;
         const float* Bs = Bs_ + buf * BK * LDT;
-        // fragments of k-step kk+2 are read from LDS while the MFMAs of k-step kk run
-        const float* ar = As + half * LDA + wm * 64 + l31;
+        // A_ROWS: step s multiplies k = s (lanes 0-31) and k = s + HS (lanes 32-63); otherwise
+        // k = 2 s and 2 s + 1.  The fragments of the next step are read from LDS while the MFMAs
+        // of this one run.
+        constexpr int KS = 2;  // LDS rows between steps (the B tile of an A_ROWS product is stored paired)
         const float* br = Bs + half * LDB + wn * WN + l31;
-        float fa0[2], fa1[2], fbn[2][TN];
-        fa0[0] = ar[0]; fa1[0] = ar[32];
+        float fbn[2][TN];
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) fbn[0][tn] = br[32 * tn];
+        if (AM == A_ROWS) {
+            const float* ar = As + (wm * 64 + l31) * LDA + HS * half;
+            float4 a0 = *reinterpret_cast<const float4*>(ar), a1 = *reinterpret_cast<const float4*>(ar + 32 * LDA);
 #pragma unroll
-        for (int kk = 0; kk < BK; kk += 2) {
-            const int cur = (kk >> 1) & 1, nxt = cur ^ 1;
-            if (kk + 2 < BK) {
-                fa0[nxt] = ar[(kk + 2) * LDA]; fa1[nxt] = ar[(kk + 2) * LDA + 32];
+            for (int s4 = 0; s4 < HS; s4 += 4) {
+                float4 n0 = a0, n1 = a1;
+                if (s4 + 4 < HS) {
+                    n0 = *reinterpret_cast<const float4*>(ar + s4 + 4);
+                    n1 = *reinterpret_cast<const float4*>(ar + 32 * LDA + s4 + 4);
+                }
+                const float av0[4] = {a0.x, a0.y, a0.z, a0.w}, av1[4] = {a1.x, a1.y, a1.z, a1.w};
 #pragma unroll
-                for (int tn = 0; tn < TN; ++tn) fbn[nxt][tn] = br[(kk + 2) * LDB + 32 * tn];
+                for (int j = 0; j < 4; ++j) {
+                    const int st = s4 + j, cur = st & 1, nxt = cur ^ 1;
+                    if (st + 1 < HS) {
+#pragma unroll
+                        for (int tn = 0; tn < TN; ++tn) fbn[nxt][tn] = br[KS * (st + 1) * LDB + 32 * tn];
+                    }
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn) {
+                        acc[0][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[j], fbn[cur][tn], acc[0][tn], 0, 0, 0);
+                        acc[1][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[j], fbn[cur][tn], acc[1][tn], 0, 0, 0);
+                    }
+                }
+                a0 = n0; a1 = n1;
             }
+        } else {
+            const float* ar = As + half * LDA + wm * 64 + l31;
+            float fa0[2], fa1[2];
+            fa0[0] = ar[0]; fa1[0] = ar[32];
 #pragma unroll
-            for (int tn = 0; tn < TN; ++tn) {
-                acc[0][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[cur], fbn[cur][tn], acc[0][tn], 0, 0, 0);
-                acc[1][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[cur], fbn[cur][tn], acc[1][tn], 0, 0, 0);
+            for (int st = 0; st < HS; ++st) {
+                const int cur = st & 1, nxt = cur ^ 1;
+                if (st + 1 < HS) {
+                    fa0[nxt] = ar[KS * (st + 1) * LDA]; fa1[nxt] = ar[KS * (st + 1) * LDA + 32];
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn) fbn[nxt][tn] = br[KS * (st + 1) * LDB + 32 * tn];
+                }
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) {
+                    acc[0][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[cur], fbn[cur][tn], acc[0][tn], 0, 0, 0);
+                    acc[1][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[cur], fbn[cur][tn], acc[1][tn], 0, 0, 0);
+                }
             }
         }
         if (DB) {
@@ -276,21 +334,33 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_kernel(GemmArgs g)
         }
     }
 
+    // One MFMA tile is 32 rows x 32 columns; a lane holds column `col` and the 16 rows
+    // (r & 3) + 8 (r >> 2) + 4 half.  Its 16 sign bits and those of lane ^ 32 make the mask word
+    // of (row block, col).  Everything the epilogue reads is requested before the first store
+    // (the memory counter of this ISA covers loads and stores alike).
+    float biasv[TN];
+    uint32_t mwordv[2][TN];
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int colc = min(n0 + wn * WN + tn * 32 + l31, g.N - 1);
+        biasv[tn] = 0.0f;
+        if (EPI == EPI_BIAS_RELU || EPI == EPI_BIAS_TANH || EPI == EPI_BIAS || EPI == EPI_BIAS_RELU_MASK)
+            biasv[tn] = g.bias[colc];
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm) {
+            mwordv[tm][tn] = 0;
+            if (EPI == EPI_MUL_MASK) mwordv[tm][tn] = g.mask[(size_t)((m0 + wm * 64 + tm * 32) >> 5) * g.N + colc];
+        }
+    }
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) {
             const int col = n0 + wn * WN + tn * 32 + l31;
             if (col >= g.N) continue;
-            float bias = 0.0f;
-            if (EPI == EPI_BIAS_RELU || EPI == EPI_BIAS_TANH || EPI == EPI_BIAS || EPI == EPI_BIAS_RELU_MASK)
-                bias = g.bias[col];
-            // One MFMA tile is 32 rows x 32 columns; a lane holds column `col` and the 16 rows
-            // (r & 3) + 8 (r >> 2) + 4 half.  Its 16 sign bits and those of lane ^ 32 make the
-            // mask word of (row block, col).
+            const float bias = biasv[tn];
             const size_t mask_at = (size_t)((m0 + wm * 64 + tm * 32) >> 5) * g.N + col;
-            uint32_t mword = 0;
-            if (EPI == EPI_MUL_MASK) mword = g.mask[mask_at];
+            uint32_t mword = mwordv[tm][tn];
             if (EPI == EPI_BIAS_RELU_MASK) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
@@ -298,20 +368,33 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_kernel(GemmArgs g)
                 mword |= (uint32_t)__shfl_xor((int)mword, 32);
                 if (half == 0) g.mask[mask_at] = mword;
             }
+            // All 16 values are finished before the first store, so that the loads they depend
+            // on (bias, mask word, aux) are waited for once and the stores go out back to back.
+            const int row_base = m0 + wm * 64 + tm * 32 + 4 * half;
+            float out[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int rbit = (r & 3) + 8 * (r >> 2) + 4 * half;
-                const int row = m0 + wm * 64 + tm * 32 + rbit;
+                const int rofs = (r & 3) + 8 * (r >> 2);
+                const int row = min(row_base + rofs, g.M - 1);  // clamped: only used to read aux
                 float v = acc[tm][tn][r];
-                if (EPI == EPI_BIAS_RELU_MASK) { v += bias; v = v > 0.0f ? v : 0.0f; }
-                if (row >= g.M) continue;
-                if (EPI == EPI_BIAS_RELU) { v += bias; v = v > 0.0f ? v : 0.0f; }
+                if (EPI == EPI_BIAS_RELU_MASK || EPI == EPI_BIAS_RELU) { v += bias; v = v > 0.0f ? v : 0.0f; }
                 else if (EPI == EPI_BIAS_TANH) v = fast_tanh(v + bias);
                 else if (EPI == EPI_BIAS) v += bias;
                 else if (EPI == EPI_MUL_DTANH) { const float h = g.aux[(size_t)row * g.ldaux + col]; v *= (1.0f - h * h); }
                 else if (EPI == EPI_MUL_DRELU) { const float h = g.aux[(size_t)row * g.ldaux + col]; v *= (h > 0.0f ? 1.0f : 0.0f); }
-                else if (EPI == EPI_MUL_MASK) { if (!((mword >> rbit) & 1u)) v = 0.0f; }
-                C[(size_t)row * g.ldc + col] = v;
+                else if (EPI == EPI_MUL_MASK) { if (!((mword >> (rofs + 4 * half)) & 1u)) v = 0.0f; }
+                out[r] = v;
+            }
+            float* cp = C + (size_t)row_base * g.ldc + col;
+            if (m0 + TM <= g.M) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) cp[(size_t)((r & 3) + 8 * (r >> 2)) * g.ldc] = out[r];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rofs = (r & 3) + 8 * (r >> 2);
+                    if (row_base + rofs < g.M) cp[(size_t)rofs * g.ldc] = out[r];
+                }
             }
         }
 }
