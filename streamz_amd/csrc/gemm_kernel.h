@@ -62,7 +62,7 @@ struct Frag4 { float v[4]; };
 __device__ __forceinline__ float fast_tanh(float x)
 {
     const float t = __expf(2.0f * fminf(fmaxf(x, -15.0f), 15.0f));
-    return 1.0f - __fdividef(2.0f, t + 1.0f);
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(t + 1.0f);  // v_rcp_f32: 1 ulp
 }
 
 __device__ __forceinline__ Frag4 load4(const float* base, int64_t row, int col, int ld, int row_max, int col_max,
@@ -368,10 +368,7 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_kernel(GemmArgs g)
                 mword |= (uint32_t)__shfl_xor((int)mword, 32);
                 if (half == 0) g.mask[mask_at] = mword;
             }
-            // All 16 values are finished before the first store, so that the loads they depend
-            // on (bias, mask word, aux) are waited for once and the stores go out back to back.
             const int row_base = m0 + wm * 64 + tm * 32 + 4 * half;
-            float out[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int rofs = (r & 3) + 8 * (r >> 2);
@@ -383,17 +380,27 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_kernel(GemmArgs g)
                 else if (EPI == EPI_MUL_DTANH) { const float h = g.aux[(size_t)row * g.ldaux + col]; v *= (1.0f - h * h); }
                 else if (EPI == EPI_MUL_DRELU) { const float h = g.aux[(size_t)row * g.ldaux + col]; v *= (h > 0.0f ? 1.0f : 0.0f); }
                 else if (EPI == EPI_MUL_MASK) { if (!((mword >> (rofs + 4 * half)) & 1u)) v = 0.0f; }
-                out[r] = v;
+                acc[tm][tn][r] = v;
             }
+        }
+    // Second pass: the stores.  Every value was finished above, in place, so everything the
+    // epilogue loads has arrived before the first store and the stores go out back to back.
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            const int col = n0 + wn * WN + tn * 32 + l31;
+            if (col >= g.N) continue;
+            const int row_base = m0 + wm * 64 + tm * 32 + 4 * half;
             float* cp = C + (size_t)row_base * g.ldc + col;
             if (m0 + TM <= g.M) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) cp[(size_t)((r & 3) + 8 * (r >> 2)) * g.ldc] = out[r];
+                for (int r = 0; r < 16; ++r) cp[(size_t)((r & 3) + 8 * (r >> 2)) * g.ldc] = acc[tm][tn][r];
             } else {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int rofs = (r & 3) + 8 * (r >> 2);
-                    if (row_base + rofs < g.M) cp[(size_t)rofs * g.ldc] = out[r];
+                    if (row_base + rofs < g.M) cp[(size_t)rofs * g.ldc] = acc[tm][tn][r];
                 }
             }
         }
