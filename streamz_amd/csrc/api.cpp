@@ -36,6 +36,20 @@ int hip_fail(hipError_t e, const char* what)
     return SZH_ENODEVICE;
 }
 
+int allow_dynamic_lds(const void* kernel, size_t bytes)
+{
+    static std::mutex mu;
+    static std::map<std::pair<const void*, int>, size_t> done;
+    int dev = 0;
+    SZ_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
+    size_t& have = done[{kernel, dev}];
+    if (have >= bytes) return SZH_OK;
+    SZ_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    have = bytes;
+    return SZH_OK;
+}
+
 namespace {
 
 struct DevBuf {

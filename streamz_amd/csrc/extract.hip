@@ -342,12 +342,7 @@ int plan_run(Plan* p, const int16_t* pcm_dev, float* feats_dev, hipStream_t stre
         set_error("device buffers must be 16-byte aligned");
         return SZH_EINVAL;
     }
-    static bool attr_set = false;
-    if (!attr_set) {
-        SZ_HIP(hipFuncSetAttribute((const void*)mfcc_base_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)kBaseLdsBytes));
-        attr_set = true;
-    }
+    if (int rc = allow_dynamic_lds((const void*)mfcc_base_kernel, kBaseLdsBytes)) return rc;
     const uint32_t wave_jobs = (p->n_segs + kBaseWaves - 1) / kBaseWaves;
     const uint32_t grid_a = wave_jobs < 256u * 2u * 8u ? wave_jobs : 256u * 2u * 8u;
     {

@@ -20,6 +20,10 @@ int hip_fail(hipError_t e, const char* what);  // records the message, returns S
         if (e__ != hipSuccess) return ::sz::hip_fail(e__, #expr); \
     } while (0)
 
+// Raises a kernel's dynamic-LDS limit to `bytes`, once per (kernel, device); callable from any
+// thread.  Kernels that ask for more than 64 KB at launch need it.
+int allow_dynamic_lds(const void* kernel, size_t bytes);
+
 // ---- extraction ----------------------------------------------------------------------
 // One unit of kernel work: up to kSegWindows consecutive windows of one file.
 constexpr uint32_t kSegWindows = 48;

@@ -530,11 +530,7 @@ int launch_vote_head(const float* h2, uint64_t rows, int H2, const float* w3, co
                      unsigned long long* counts, double* psums, hipStream_t s)
 {
     const size_t lds = vote_lds_bytes(H2, NCB);
-    static bool attr_set = false;
-    if (!attr_set) {
-        SZ_HIP(hipFuncSetAttribute((const void*)vote_head_kernel<NCB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kVoteLdsMax));
-        attr_set = true;
-    }
+    if (int rc = allow_dynamic_lds((const void*)vote_head_kernel<NCB>, kVoteLdsMax)) return rc;
     const uint64_t groups = (rows + 15) / 16;
     const unsigned blocks = (unsigned)std::min<uint64_t>((groups + 3) / 4, 2048);
     ProfScope prof("vote_head", s);
@@ -1387,11 +1383,7 @@ template <int KB, int NCB, int WAVES>
 int launch_head_wide_one(const HeadArgs& h, int blocks, hipStream_t s)
 {
     const size_t lds = (size_t)2 * NCB * KB * 64 * sizeof(float4);
-    static bool attr_set = false;
-    if (!attr_set) {
-        SZ_HIP(hipFuncSetAttribute((const void*)head_wide_kernel<KB, NCB, WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    if (int rc = allow_dynamic_lds((const void*)head_wide_kernel<KB, NCB, WAVES>, lds)) return rc;
     hipLaunchKernelGGL((head_wide_kernel<KB, NCB, WAVES>), dim3(blocks), dim3(64 * WAVES), lds, s, h);
     return SZH_OK;
 }
@@ -1504,14 +1496,10 @@ int net_accumulate(Net* n, const AccumArgs& a, hipStream_t s)
                 const int ldh = (int)n->h2 + 4;
                 const size_t lds = sizeof(float) * ((size_t)kHeadRows * ldh + (size_t)n->h2 * h.Cp +
                                                     (size_t)h.Cp * ldh + (size_t)kHeadRows * h.Cp);
-                static bool attr_set = false;
-                if (!attr_set) {
-                    const void* fns[] = {(const void*)head_kernel<4>, (const void*)head_kernel<8>,
-                                         (const void*)head_kernel<16>, (const void*)head_kernel<32>};
-                    for (const void* fn : fns)
-                        SZ_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024));
-                    attr_set = true;
-                }
+                const void* fn = h.Cp == 4 ? (const void*)head_kernel<4> : h.Cp == 8 ? (const void*)head_kernel<8>
+                               : h.Cp == 16 ? (const void*)head_kernel<16> : (const void*)head_kernel<32>;
+                rc = allow_dynamic_lds(fn, 112 * 1024);
+                if (rc) return rc;
                 if (h.Cp == 4) hipLaunchKernelGGL(head_kernel<4>, dim3(blocks), dim3(kHeadThreads), lds, s, h);
                 else if (h.Cp == 8) hipLaunchKernelGGL(head_kernel<8>, dim3(blocks), dim3(kHeadThreads), lds, s, h);
                 else if (h.Cp == 16) hipLaunchKernelGGL(head_kernel<16>, dim3(blocks), dim3(kHeadThreads), lds, s, h);
