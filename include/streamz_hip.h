@@ -194,6 +194,16 @@ int szh_identify_speaker_list(szh_net *net, szh_extractor *ext, const int16_t *p
 int szh_identify_speaker_list_dev(szh_net *net, szh_extractor *ext, const int16_t *pcm_dev, uint64_t n_samples,
                                   float threshold, uint32_t tile_windows, uint32_t *ids, uint32_t capacity,
                                   uint32_t *n_ids, uint64_t *counts);
+/* Pooled embedding of feature rows, unit norm (normalize, lib.rs:132-139), out[hidden2]:
+ *   mode 0  extract_embedding_from_features, lib.rs:1450-1471: mean of forward_embedding
+ *   mode 1  median_embedding_from_features, lib.rs:1474-1495: per-dimension median of forward_embedding
+ *   mode 2  per-dimension median of embed (the pooling of extract_embedding, lib.rs:1433-1446)
+ * No windows give the zero vector.  The medians are exact order statistics (radix selection on the
+ * device); the mean is accumulated in f64. */
+int szh_net_pooled_embedding(szh_net *net, const float *feats, uint64_t n_windows, int mode, float *out);
+/* extract_embedding, lib.rs:1418-1447: extract, embed every window, per-dimension median, unit norm. */
+int szh_extract_embedding(szh_net *net, szh_extractor *ext, const int16_t *pcm, uint64_t n_samples, float *out);
+
 /* identify_speaker, lib.rs:1285-1303: the class whose window probabilities sum highest (the last
  * maximum wins; 0 for a net without outputs).  sums (optional, output_size entries) receives the
  * per-class sums.  They are accumulated in f64 on the device and compared as f32; the reference

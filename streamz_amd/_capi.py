@@ -71,6 +71,8 @@ _SIGS = {
                                                       C.POINTER(C.c_int64)]),
     "szh_identify_speaker_with_threshold_feats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_float,
                                                             C.POINTER(C.c_int64), C.c_void_p]),
+    "szh_net_pooled_embedding": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p]),
+    "szh_extract_embedding": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
     "szh_identify_from_features": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_float, C.c_void_p, C.c_uint32,
                                              C.POINTER(C.c_uint32), C.c_void_p]),
     "szh_net_grad_len": (C.c_uint64, [C.c_void_p]),
@@ -460,6 +462,31 @@ def identify_speaker_with_threshold_feats(net, windows, threshold, return_sums=F
     _check(lib().szh_identify_speaker_with_threshold_feats(net._h, _p(f), f.shape[0], threshold, C.byref(r), _p(sums)))
     got = None if r.value < 0 else int(r.value)
     return (got, sums[:net.output_size()].copy()) if return_sums else got
+
+
+def _pooled(net, feats, mode):
+    f = np.ascontiguousarray(feats, np.float32).reshape(-1, FEATURE_SIZE)
+    out = np.zeros(net.dims()[2], np.float32)
+    _check(lib().szh_net_pooled_embedding(net._h, _p(f), f.shape[0], mode, _p(out)))
+    return out
+
+
+def extract_embedding_from_features(net, feats):
+    """extract_embedding_from_features (lib.rs:1450-1471)."""
+    return _pooled(net, feats, 0)
+
+
+def median_embedding_from_features(net, feats):
+    """median_embedding_from_features (lib.rs:1474-1495)."""
+    return _pooled(net, feats, 1)
+
+
+def extract_embedding(net, sample, extractor):
+    """extract_embedding (lib.rs:1418-1447)."""
+    pcm = np.ascontiguousarray(sample, np.int16)
+    out = np.zeros(net.dims()[2], np.float32)
+    _check(lib().szh_extract_embedding(net._h, extractor._h, _p(pcm), pcm.size, _p(out)))
+    return out
 
 
 def identify_speaker_list_dev(net, pcm_dev_ptr, n_samples, threshold, extractor, tile_windows=0):

@@ -5,6 +5,7 @@
 #include <sys/stat.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -657,6 +658,64 @@ int szh_pretrain_network(szh_net* net, szh_extractor* ext, const int16_t* pcm, u
     if (!net || !ext || !mean_loss || (n_samples && !pcm)) { set_error("null argument"); return SZH_EINVAL; }
     return pretrain_network_host(reinterpret_cast<Net*>(net), reinterpret_cast<Extractor*>(ext), pcm, n_samples, target_class,
                                  num_classes, epochs, lr, dropout, batch_size, aug, rng, mean_loss);
+    SZ_CATCH
+}
+
+// normalize, lib.rs:132-139
+static void normalize_vec(float* v, uint32_t d)
+{
+    float ss = 0.0f;
+    for (uint32_t i = 0; i < d; ++i) ss += v[i] * v[i];
+    const float norm = std::sqrt(ss);
+    if (norm > 1e-6f)
+        for (uint32_t i = 0; i < d; ++i) v[i] /= norm;
+}
+
+int szh_net_pooled_embedding(szh_net* net, const float* feats, uint64_t n_windows, int mode, float* out)
+{
+    SZ_TRY
+    if (!net || !out || (n_windows && !feats) || mode < 0 || mode > 2) { set_error("bad argument"); return SZH_EINVAL; }
+    Net* n = reinterpret_cast<Net*>(net);
+    std::lock_guard<std::mutex> lock(n->mu);
+    DevBuf d_feats;
+    if (n_windows) {
+        const int rc = d_feats.alloc(n_windows * n->in * sizeof(float));
+        if (rc) return rc;
+        SZ_HIP(hipMemcpy(d_feats.p, feats, n_windows * n->in * sizeof(float), hipMemcpyHostToDevice));
+    }
+    const int rc = net_pool_host(n, d_feats.as<float>(), n_windows, mode, out);
+    if (rc) return rc;
+    normalize_vec(out, n->h2);
+    return SZH_OK;
+    SZ_CATCH
+}
+
+int szh_extract_embedding(szh_net* net, szh_extractor* ext, const int16_t* pcm, uint64_t n_samples, float* out)
+{
+    SZ_TRY
+    if (!net || !ext || !out || (n_samples && !pcm)) { set_error("null argument"); return SZH_EINVAL; }
+    Net* n = reinterpret_cast<Net*>(net);
+    Extractor* e = reinterpret_cast<Extractor*>(ext);
+    if (n->in != (uint32_t)kFeat) { set_error("extract_embedding needs a net with 60 inputs"); return SZH_EINVAL; }
+    std::lock_guard<std::mutex> lock(n->mu);
+    const uint64_t nw = szh_window_count(n_samples);
+    DevBuf d_pcm, d_feat;
+    Plan* plan = nullptr;
+    struct PlanGuard { Plan*& p; ~PlanGuard() { plan_destroy(p); } } guard{plan};
+    if (nw) {
+        const uint64_t off = 0;
+        int rc = plan_create(e, &off, &n_samples, 1, &plan);
+        if (rc == SZH_OK) rc = d_pcm.alloc(n_samples * sizeof(int16_t));
+        if (rc == SZH_OK) rc = d_feat.alloc(nw * kFeat * sizeof(float));
+        if (rc) return rc;
+        SZ_HIP(hipMemcpy(d_pcm.p, pcm, n_samples * sizeof(int16_t), hipMemcpyHostToDevice));
+        rc = plan_run(plan, d_pcm.as<int16_t>(), d_feat.as<float>(), nullptr);
+        if (rc) return rc;
+    }
+    const int rc = net_pool_host(n, d_feat.as<float>(), nw, 2, out);
+    if (rc) return rc;
+    normalize_vec(out, n->h2);
+    return SZH_OK;
     SZ_CATCH
 }
 

@@ -151,6 +151,9 @@ int net_read_totals(Net* n, hipStream_t s, double* loss_sum, double* live_rows);
 // to what the arrays hold
 int net_vote_dev(Net* n, const float* x_dev, uint64_t rows, float threshold, unsigned long long* counts_dev,
                  double* psums_dev, hipStream_t s);
+// Pooled embedding (un-normalised) of device feature rows, written to host memory out[hidden2]:
+// mode 0 mean of forward_embedding, 1 median of forward_embedding, 2 median of embed.
+int net_pool_host(Net* n, const float* x_dev, uint64_t rows, int mode, float* out);
 // sizes the workspace for calls of up to `rows` rows, so that later calls allocate nothing
 int net_reserve_rows(Net* n, uint64_t rows);
 // identify_speaker_list's vote counts for a long recording, tile by tile (stream.cpp).  pcm is a

@@ -1583,6 +1583,107 @@ int net_apply(Net* n, float lr, hipStream_t s)
     return SZH_OK;
 }
 
+// ---- pooled embeddings --------------------------------------------------------------------
+// Per-column order statistic of E[rows][D] by radix selection, 8 bits per pass: a workgroup owns
+// 32 columns and keeps a 256-bin histogram per column in LDS; after each pass one thread per
+// column picks the bin that holds rank k and narrows the key prefix.  Floats are compared through
+// the usual order-preserving map to unsigned keys.
+constexpr int kMedCols = 32;
+constexpr int kMedLd = 257;  // histogram row stride: columns that hit the same bin use different banks
+
+__device__ __forceinline__ uint32_t float_key(float v)
+{
+    const uint32_t u = __float_as_uint(v);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key_float(uint32_t k)
+{
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+
+// out[which][col] = the element of rank k[which] (0-based, ascending) of column col
+__global__ __launch_bounds__(256) void column_select_kernel(const float* __restrict__ E, uint64_t rows, int D, uint64_t k0,
+                                                           uint64_t k1, float* __restrict__ out)
+{
+    __shared__ unsigned int hist[kMedCols * kMedLd];
+    __shared__ uint32_t prefix[kMedCols];
+    __shared__ unsigned long long rank[kMedCols];
+    const int c = threadIdx.x & (kMedCols - 1), phase = threadIdx.x / kMedCols;
+    const int col = blockIdx.x * kMedCols + c;
+    for (int which = 0; which < 2; ++which) {
+        if (threadIdx.x < kMedCols) { prefix[threadIdx.x] = 0; rank[threadIdx.x] = which ? k1 : k0; }
+        for (int shift = 24; shift >= 0; shift -= 8) {
+            for (int e = threadIdx.x; e < kMedCols * kMedLd; e += 256) hist[e] = 0;
+            __syncthreads();
+            if (col < D) {
+                const uint32_t want = prefix[c];
+                for (uint64_t r = phase; r < rows; r += 256 / kMedCols) {
+                    const uint32_t key = float_key(E[r * D + col]);
+                    // keys that agree with the prefix chosen so far in the bits above this byte
+                    if (shift == 24 || (key >> (shift + 8)) == (want >> (shift + 8)))
+                        atomicAdd(&hist[c * kMedLd + ((key >> shift) & 255u)], 1u);
+                }
+            }
+            __syncthreads();
+            if (threadIdx.x < kMedCols) {
+                unsigned long long k = rank[threadIdx.x];
+                int bin = 0;
+                for (; bin < 255; ++bin) {
+                    const unsigned int h = hist[threadIdx.x * kMedLd + bin];
+                    if (k < h) break;
+                    k -= h;
+                }
+                rank[threadIdx.x] = k;
+                prefix[threadIdx.x] |= (uint32_t)bin << shift;
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x < kMedCols && blockIdx.x * kMedCols + threadIdx.x < D)
+            out[(size_t)which * D + blockIdx.x * kMedCols + threadIdx.x] = key_float(prefix[threadIdx.x]);
+        __syncthreads();
+    }
+}
+
+// Pooled embedding of `rows` feature rows, un-normalised, to the host: mode 0 = mean of
+// forward_embedding (lib.rs:1451-1466), 1 = per-dimension median of forward_embedding
+// (lib.rs:1482-1492), 2 = per-dimension median of embed (lib.rs:1433-1443).
+int net_pool_host(Net* n, const float* x_dev, uint64_t rows, int mode, float* out)
+{
+    const uint32_t D = n->h2;
+    for (uint32_t i = 0; i < D; ++i) out[i] = 0.0f;
+    if (rows == 0 || D == 0) return SZH_OK;
+    const ForwardKind kind = mode == 2 ? kFwdEmbedTanh : kFwdEmbedRelu;
+    float* E = nullptr;
+    double* d_aux = nullptr;
+    SZ_HIP(hipMalloc((void**)&E, rows * D * sizeof(float)));
+    hipError_t he = hipMalloc((void**)&d_aux, 2 * (size_t)D * sizeof(double));
+    int rc = he == hipSuccess ? SZH_OK : hip_fail(he, "pooling buffers");
+    if (rc == SZH_OK) rc = net_forward_dev(n, x_dev, rows, E, kind, nullptr);
+    if (rc == SZH_OK && mode == 0) {
+        std::vector<double> sums(D);
+        he = hipMemsetAsync(d_aux, 0, D * sizeof(double), nullptr);
+        if (he == hipSuccess) {
+            hipLaunchKernelGGL(prob_sum_kernel, dim3((unsigned)std::min<uint64_t>((rows + 63) / 64, 1024)), dim3(256), 0, nullptr,
+                               E, rows, (int)D, d_aux);
+            he = hipMemcpy(sums.data(), d_aux, D * sizeof(double), hipMemcpyDeviceToHost);
+        }
+        if (he != hipSuccess) rc = hip_fail(he, "mean pooling");
+        else for (uint32_t i = 0; i < D; ++i) out[i] = (float)sums[i] / (float)rows;
+    } else if (rc == SZH_OK) {
+        std::vector<float> sel(2 * (size_t)D);
+        float* d_sel = reinterpret_cast<float*>(d_aux);
+        const uint64_t mid = rows / 2;
+        hipLaunchKernelGGL(column_select_kernel, dim3((D + kMedCols - 1) / kMedCols), dim3(256), 0, nullptr, E, rows, (int)D,
+                           rows % 2 == 0 ? mid - 1 : mid, mid, d_sel);
+        he = hipMemcpy(sel.data(), d_sel, 2 * (size_t)D * sizeof(float), hipMemcpyDeviceToHost);
+        if (he != hipSuccess) rc = hip_fail(he, "median pooling");
+        else for (uint32_t i = 0; i < D; ++i) out[i] = rows % 2 == 0 ? (sel[i] + sel[D + i]) / 2.0f : sel[D + i];
+    }
+    (void)hipFree(E);
+    if (d_aux) (void)hipFree(d_aux);
+    return rc;
+}
+
 int net_reserve_rows(Net* n, uint64_t rows) { return ensure_workspace(n, rows); }
 
 int net_vote_dev(Net* n, const float* x_dev, uint64_t rows, float threshold, unsigned long long* counts_dev,

@@ -348,51 +348,29 @@ inline size_t identify_speaker_with_threshold_feats(const SimpleNeuralNet& net, 
     return id < 0 ? (size_t)-1 : (size_t)id;
 }
 
-// per-dimension median over the rows of e[n][d], unit norm (lib.rs:1433-1446, 1482-1494)
-inline std::vector<float> median_rows(const std::vector<float>& e, size_t n, size_t d)
-{
-    std::vector<float> emb(d, 0.0f), vals(n);
-    if (n == 0) return emb;
-    for (size_t i = 0; i < d; ++i) {
-        for (size_t w = 0; w < n; ++w) vals[w] = e[w * d + i];
-        std::sort(vals.begin(), vals.end());
-        const size_t mid = n / 2;
-        emb[i] = (n % 2 == 0) ? (vals[mid - 1] + vals[mid]) / 2.0f : vals[mid];
-    }
-    normalize(emb);
-    return emb;
-}
-
 // extract_embedding, lib.rs:1418-1447: median of embed (tanh layer) over the sample's windows
 inline std::vector<float> extract_embedding(const SimpleNeuralNet& net, const std::vector<int16_t>& sample,
                                             const FeatureExtractor& ext)
 {
-    const Features wins = ext.extract(sample);
-    if (wins.is_empty()) return std::vector<float>(net.embedding_size(), 0.0f);
-    return median_rows(net.embed_rows(wins.data.data(), wins.len()), wins.len(), net.embedding_size());
+    std::vector<float> emb(net.embedding_size(), 0.0f);
+    check(szh_extract_embedding(net.handle(), ext.handle(), sample.data(), sample.size(), emb.data()));
+    return emb;
 }
 
 // extract_embedding_from_features, lib.rs:1450-1471: mean of forward_embedding, unit norm
 inline std::vector<float> extract_embedding_from_features(const SimpleNeuralNet& net, const Features& feats)
 {
-    const size_t d = net.embedding_size(), n = feats.len();
-    std::vector<float> acc(d, 0.0f);
-    if (n > 0) {
-        const std::vector<float> e = net.forward_embedding_rows(feats.data.data(), n);
-        for (size_t w = 0; w < n; ++w)
-            for (size_t i = 0; i < d; ++i) acc[i] += e[w * d + i];
-        for (float& v : acc) v /= (float)n;
-    }
-    normalize(acc);
-    return acc;
+    std::vector<float> emb(net.embedding_size(), 0.0f);
+    check(szh_net_pooled_embedding(net.handle(), feats.data.data(), feats.len(), 0, emb.data()));
+    return emb;
 }
 
 // median_embedding_from_features, lib.rs:1474-1495
 inline std::vector<float> median_embedding_from_features(const SimpleNeuralNet& net, const Features& feats)
 {
-    const size_t d = net.embedding_size(), n = feats.len();
-    if (n == 0) return std::vector<float>(d, 0.0f);
-    return median_rows(net.forward_embedding_rows(feats.data.data(), n), n, d);
+    std::vector<float> emb(net.embedding_size(), 0.0f);
+    check(szh_net_pooled_embedding(net.handle(), feats.data.data(), feats.len(), 1, emb.data()));
+    return emb;
 }
 
 // identify_speaker_from_embedding, lib.rs:1499-1529 (SIZE_MAX = no match)

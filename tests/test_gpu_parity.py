@@ -362,6 +362,59 @@ def test_identify_speaker_list_end_to_end(sz, po, ext, oext):
     assert sz.identify_speaker_list(net, pcm[:700], thr, ext) == []
 
 
+def _ref_normalize(v):
+    v = v.astype(np.float32).copy()
+    ss = np.float32(0.0)
+    for x in v:  # sum::<f32>() in order, lib.rs:133
+        ss = np.float32(ss + np.float32(x * x))
+    norm = np.float32(np.sqrt(ss))
+    return v / norm if norm > 1e-6 else v
+
+
+def _ref_median(e):
+    n = e.shape[0]
+    if n == 0:
+        return np.zeros(e.shape[1], np.float32)
+    srt = np.sort(e, axis=0)
+    mid = n // 2
+    med = (srt[mid - 1] + srt[mid]) / np.float32(2.0) if n % 2 == 0 else srt[mid]
+    return _ref_normalize(med)
+
+
+@pytest.mark.parametrize("dims", [(60, 64, 24, 3), (60, 128, 40, 5), (60, 512, 256, 16)])
+def test_pooled_embeddings(sz, po, ext, oext, dims):
+    """extract_embedding, extract_embedding_from_features, median_embedding_from_features
+    (lib.rs:1418-1495): pooled on the device, against the oracle's per-window embeddings pooled
+    with the reference's formulas, and the selection itself exactly against a sort of the
+    device's own embeddings."""
+    rng = np.random.default_rng(sum(dims))
+    onet = po.Net(*dims)
+    params = [rng.uniform(-0.5, 0.5, s).astype(np.float32) for s in onet.shapes()]
+    onet.set_params(params)
+    net = sz.SimpleNeuralNet(*dims, init=params)
+    pcm = np.clip(np.round(0.3 * rng.standard_normal(400 * 120 + 800) * 32767), -32768, 32767).astype(np.int16)
+    feats = oext.extract(pcm, fft_mode=0)
+    for n in (feats.shape[0], feats.shape[0] - 1, 2, 1, 0):
+        f = feats[:n]
+        e_relu = onet.forward_embedding(f).reshape(n, dims[2])
+        e_tanh = onet.embed(f).reshape(n, dims[2])
+        # mean: f32 accumulation in window order, / count, unit norm (lib.rs:1451-1470)
+        acc = np.zeros(dims[2], np.float32)
+        for row in e_relu:
+            acc = (acc + row).astype(np.float32)
+        want_mean = _ref_normalize(acc / np.float32(n)) if n else acc
+        np.testing.assert_allclose(sz.extract_embedding_from_features(net, f), want_mean, atol=1e-4)
+        np.testing.assert_allclose(sz.median_embedding_from_features(net, f), _ref_median(e_relu), atol=1e-4)
+        # the order statistic is exact: same answer as sorting the device's own embeddings
+        # (ReLU leaves many exact zeros, so ties are covered)
+        own = net.forward_embedding(f).reshape(n, dims[2]) if n else np.zeros((0, dims[2]), np.float32)
+        np.testing.assert_allclose(sz.median_embedding_from_features(net, f), _ref_median(own), atol=1e-7)
+    np.testing.assert_allclose(sz.extract_embedding(net, pcm, ext), _ref_median(onet.embed(feats).reshape(-1, dims[2])), atol=1e-4)
+    own = net.embed(ext.extract(pcm))
+    np.testing.assert_allclose(sz.extract_embedding(net, pcm, ext), _ref_median(own.reshape(-1, dims[2])), atol=1e-7)
+    assert not sz.extract_embedding(net, pcm[:100], ext).any()  # lib.rs:1429-1431
+
+
 def test_add_output_class_and_clone(sz):
     rng = np.random.default_rng(2)
     net = sz.SimpleNeuralNet(60, 16, 8, 2, seed=3)
