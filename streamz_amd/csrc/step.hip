@@ -35,6 +35,7 @@ constexpr int kStepThreads = 256;
 constexpr int kStepRows = 8;   // most rows of one optimiser step
 constexpr int kStepHS = 32;    // hidden-1 units per workgroup
 constexpr int kStepMaxC = 32;
+constexpr int kStepLdW1 = kStepHS + 16;  // row stride of w1 in LDS: rows k and k+1 sit 16 banks apart
 
 struct StepArgs {
     float* params;           // [w1|b1|w2|b2|w3|b3]
@@ -49,30 +50,31 @@ struct StepArgs {
     uint32_t epochs, bs;
     float lr;
     float* part;             // [2][workgroups][8][h2]
-    unsigned* counter;       // grid barrier, zero at launch
+    unsigned* counter;       // grid barrier: one arrival count per workgroup, zero at launch
     int* abort_flag;         // set when a barrier gives up (never in a healthy run)
     double* totals;          // += {loss, live rows}
 };
 
-// All workgroups arrive, then all leave.  `target` = workgroups x (barriers so far + 1).
-__device__ bool grid_barrier(unsigned* counter, unsigned target, int* abort_flag)
+// All workgroups arrive, then all leave.  Workgroup b publishes the number of barriers it has
+// reached in flags[b] (a plain release store: no read-modify-write that would queue up behind the
+// other workgroups' at one address); one lane per workgroup then waits for that workgroup's flag.
+__device__ bool grid_barrier(unsigned* flags, int n_blocks, unsigned arrived, int* abort_flag)
 {
     __shared__ int ok;
     __threadfence();   // this thread's global writes are visible device-wide
+    if (threadIdx.x == 0) ok = 1;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        atomicAdd(counter, 1u);
+    if (threadIdx.x == 0) __hip_atomic_store(&flags[blockIdx.x], arrived, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    if ((int)threadIdx.x < n_blocks) {
         unsigned spins = 0;
-        int good = 1;
-        while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            __builtin_amdgcn_s_sleep(2);
+        while (__hip_atomic_load(&flags[threadIdx.x], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < arrived) {
+            __builtin_amdgcn_s_sleep(1);
             if (++spins > (1u << 24) || __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
                 __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                good = 0;
+                ok = 0;
                 break;
             }
         }
-        ok = good;
     }
     __syncthreads();
     __threadfence();   // later reads see what the other workgroups wrote before arriving
@@ -88,20 +90,28 @@ __device__ __forceinline__ float dpp16(float v)
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
 }
 
+// tanh from the hardware exponential and reciprocal; absolute error ~1e-7
+__device__ __forceinline__ float step_tanh(float x)
+{
+    const float t = __expf(2.0f * fminf(fmaxf(x, -15.0f), 15.0f));
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(t + 1.0f);
+}
+
 // LDS layout, shared by the kernel and the host-side size computation (floats, every piece on a
 // 16-byte boundary)
 struct StepLds {
     int w1, b1, w2, b2, w3, b3, tgt, xs, h1, d1, h2, d2, d3, red, total;
-    int ld2, ld3, ldd3, cw;
+    int ld2, ld3, ldd3, cw, k4;
     __host__ __device__ StepLds(int in, int h2n, int c)
     {
         cw = (c + 15) / 16 * 16;   // class columns, padded to whole 16-wide MFMA tiles
         ld2 = h2n + 1;             // odd strides: rows read by different lanes hit different banks
         ld3 = cw + 1;
         ldd3 = cw + 4;             // delta3 rows are read as float4
+        k4 = (in + 3) & ~3;        // K of the first layer, padded to whole MFMA steps (rows >= in are zero)
         int at = 0;
         auto take = [&](int n) { const int p = at; at += (n + 3) & ~3; return p; };
-        w1 = take(in * kStepHS); b1 = take(kStepHS); w2 = take(kStepHS * ld2); b2 = take(h2n);
+        w1 = take(k4 * kStepLdW1); b1 = take(kStepHS); w2 = take(kStepHS * ld2); b2 = take(h2n);
         w3 = take(h2n * ld3); b3 = take(cw); tgt = take(cw); xs = take(kStepRows * in);
         h1 = take(kStepHS * kStepRows); d1 = take(kStepRows * kStepHS);
         h2 = take(16 * ld2); d2 = take(16 * ld2); d3 = take(kStepRows * ldd3);
@@ -117,9 +127,10 @@ __global__ __launch_bounds__(kStepThreads) void step_kernel(StepArgs a)
     const int NB = gridDim.x, blk = blockIdx.x;
     const int IN = a.in, H2 = a.h2, C = a.out, HS = kStepHS;
     const StepLds L(IN, H2, C);
-    const int LD2 = L.ld2, LD3 = L.ld3, LDD3 = L.ldd3, CW = L.cw;
+    const int LD2 = L.ld2, LD3 = L.ld3, LDD3 = L.ldd3, CW = L.cw, K4 = L.k4;
+    constexpr int LDW1 = kStepLdW1;
     const int i0 = blk * HS;
-    float* __restrict__ W1s = sm + L.w1;   // [IN][HS]
+    float* __restrict__ W1s = sm + L.w1;   // [K4][LDW1], rows >= IN zero
     float* __restrict__ b1s = sm + L.b1;   // [HS]
     float* __restrict__ W2s = sm + L.w2;   // [HS][LD2]
     float* __restrict__ b2s = sm + L.b2;   // [H2]
@@ -139,7 +150,7 @@ __global__ __launch_bounds__(kStepThreads) void step_kernel(StepArgs a)
     const float* P = a.params;
     const size_t off_b1 = (size_t)IN * a.h1, off_w2 = off_b1 + a.h1, off_b2 = off_w2 + (size_t)a.h1 * H2,
                  off_w3 = off_b2 + H2, off_b3 = off_w3 + (size_t)H2 * C;
-    for (int e = tid; e < IN * HS; e += kStepThreads) { const int j = e / HS, i = e - j * HS; W1s[e] = P[(size_t)j * a.h1 + i0 + i]; }
+    for (int e = tid; e < K4 * HS; e += kStepThreads) { const int j = e / HS, i = e - j * HS; W1s[j * LDW1 + i] = j < IN ? P[(size_t)j * a.h1 + i0 + i] : 0.0f; }
     for (int e = tid; e < HS; e += kStepThreads) b1s[e] = P[off_b1 + i0 + e];
     for (int e = tid; e < HS * H2; e += kStepThreads) { const int i = e / H2, k = e - i * H2; W2s[i * LD2 + k] = P[off_w2 + (size_t)(i0 + i) * H2 + k]; }
     for (int e = tid; e < H2; e += kStepThreads) b2s[e] = P[off_b2 + e];
@@ -197,41 +208,61 @@ __global__ __launch_bounds__(kStepThreads) void step_kernel(StepArgs a)
             for (int r = 0; r < kStepRows; ++r) n += live_s[r];
             n_live_s = n;
         }
-        // 2. own hidden-1 units: thread = (row r, unit i)
-        {
-            const int r = tid / HS, i = tid - r * HS;
-            float s0 = b1s[i], s1 = 0.0f;
-            int j = 0;
-#pragma unroll 6
-            for (; j + 1 < IN; j += 2) {
-                s0 += xs[r * IN + j] * W1s[j * HS + i];
-                s1 += xs[r * IN + j + 1] * W1s[(j + 1) * HS + i];
+        // 2. own hidden-1 units on the matrix cores: rows x units, K = inputs; wave w takes units
+        // [16 w, 16 w + 16).  Result register v of lane (unit m16, g4) is row 4 g4 + v.
+        if (wave < HS / 16) {
+            const int ib = wave * 16;
+            // all fragments first (at most 16 steps: 64 inputs), then the chain of MFMAs
+            float av[16], bv[16];
+#pragma unroll
+            for (int st = 0; st < 16; ++st) {
+                const int k = 4 * st + g4;
+                av[st] = (m16 < kStepRows && k < IN) ? xs[m16 * IN + k] : 0.0f;
+                bv[st] = k < K4 ? W1s[k * LDW1 + ib + m16] : 0.0f;
             }
-            if (j < IN) s0 += xs[r * IN + j] * W1s[j * HS + i];
-            const float s = s0 + s1;
-            h1s[i * kStepRows + r] = s > 0.0f ? s : 0.0f;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int st = 0; st < 16; st += 2) {
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[st], bv[st], acc, 0, 0, 0);  // zero fragments past K4
+                acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[st + 1], bv[st + 1], acc2, 0, 0, 0);
+            }
+            acc += acc2;
+            if (g4 < 2) {
+                const float b = b1s[ib + m16];
+                float4 o;
+                o.x = fmaxf(acc[0] + b, 0.0f); o.y = fmaxf(acc[1] + b, 0.0f);
+                o.z = fmaxf(acc[2] + b, 0.0f); o.w = fmaxf(acc[3] + b, 0.0f);
+                *reinterpret_cast<float4*>(h1s + (ib + m16) * kStepRows + 4 * g4) = o;
+            }
         }
         __syncthreads();
         // 3. partial second layer: thread = column k
         const unsigned buf = (unsigned)(step & 1);
         float* my_part = a.part + ((size_t)buf * NB + blk) * kStepRows * H2;
-        if (tid < H2) {
-            float acc[kStepRows];
+        {
+            float af[kStepHS / 4];  // h1[row m16][unit 4 st + g4], shared by every column tile
 #pragma unroll
-            for (int r = 0; r < kStepRows; ++r) acc[r] = 0.0f;
-#pragma unroll 8
-            for (int i = 0; i < HS; ++i) {
-                const float w = W2s[i * LD2 + tid];
-                const float4 ha = *reinterpret_cast<const float4*>(h1s + i * kStepRows);
-                const float4 hb = *reinterpret_cast<const float4*>(h1s + i * kStepRows + 4);
-                acc[0] += ha.x * w; acc[1] += ha.y * w; acc[2] += ha.z * w; acc[3] += ha.w * w;
-                acc[4] += hb.x * w; acc[5] += hb.y * w; acc[6] += hb.z * w; acc[7] += hb.w * w;
+            for (int st = 0; st < kStepHS / 4; ++st) af[st] = m16 < kStepRows ? h1s[(4 * st + g4) * kStepRows + m16] : 0.0f;
+            const int nt = H2 / 16;  // column tiles; wave w takes tiles w, w + 4, w + 8, w + 12
+            f32x4 acc[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int st = 0; st < kStepHS / 4; ++st)
+#pragma unroll
+                for (int u = 0; u < 4; ++u)  // a tile index past the end is clamped and its result dropped
+                    acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[st], W2s[(4 * st + g4) * LD2 + 16 * min(wave + 4 * u, nt - 1) + m16], acc[u], 0, 0, 0);
+            if (g4 < 2) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (wave + 4 * u < nt) {
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) my_part[(4 * g4 + v) * H2 + 16 * (wave + 4 * u) + m16] = acc[u][v];
+                    }
             }
-#pragma unroll
-            for (int r = 0; r < kStepRows; ++r) my_part[r * H2 + tid] = acc[r];
         }
         // 4. everybody's partials are out
-        healthy = grid_barrier(a.counter, (unsigned)(NB * (step + 1)), a.abort_flag);
+        healthy = grid_barrier(a.counter, NB, (unsigned)(step + 1), a.abort_flag);
         if (!healthy) break;
         // 5a. h2 = tanh(b2 + sum of the partials).  Wave w sums workgroups w, w+4, ... with 16-byte
         // loads (4 columns per lane), all issued before the first add; the four waves' sums are
@@ -270,7 +301,7 @@ __global__ __launch_bounds__(kStepThreads) void step_kernel(StepArgs a)
             for (int r = 0; r < kStepRows; ++r) {
                 const float t = (red[(0 * kStepRows + r) * H2 + tid] + red[(1 * kStepRows + r) * H2 + tid]) +
                                 (red[(2 * kStepRows + r) * H2 + tid] + red[(3 * kStepRows + r) * H2 + tid]);
-                h2s[r * LD2 + tid] = tanhf(b2s[tid] + t);
+                h2s[r * LD2 + tid] = step_tanh(b2s[tid] + t);
             }
         }
         __syncthreads();
@@ -311,62 +342,85 @@ __global__ __launch_bounds__(kStepThreads) void step_kernel(StepArgs a)
         __syncthreads();
         const int n_live = n_live_s;
         const float scale = n_live > 0 ? a.lr / (float)n_live : 0.0f;  // lib.rs:1047
-        // delta2 = (delta3 . w3^T)(1 - h2^2), lib.rs:1034: thread = column k
-        float w3r[2 * 16];  // this thread's row of w3
-        if (tid < H2) {
+        // delta2 = (delta3 . w3^T)(1 - h2^2), lib.rs:1034, on the matrix cores: rows x columns of
+        // h2, K = classes; column tiles are dealt to the waves
+        {
+            float af[kStepMaxC / 4];  // delta3[row m16][class 4 st + g4]
 #pragma unroll
-            for (int c = 0; c < 32; ++c) w3r[c] = c < CW ? W3s[tid * LD3 + c] : 0.0f;
+            for (int st = 0; st < kStepMaxC / 4; ++st)  // zero past the classes: those steps add nothing
+                af[st] = (4 * st < CW && m16 < kStepRows) ? d3s[m16 * LDD3 + 4 * st + g4] : 0.0f;
+            const int nt = H2 / 16;
+            f32x4 acc[4];
 #pragma unroll
-            for (int r = 0; r < kStepRows; ++r) {
-                float s = 0.0f;
+            for (int u = 0; u < 4; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int c = 0; c < 32; c += 4) {
-                    if (c < CW) {
-                        const float4 d = *reinterpret_cast<const float4*>(d3s + r * LDD3 + c);
-                        s += d.x * w3r[c] + d.y * w3r[c + 1] + d.z * w3r[c + 2] + d.w * w3r[c + 3];
+            for (int st = 0; st < kStepMaxC / 4; ++st)
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[st], W3s[(16 * min(wave + 4 * u, nt - 1) + m16) * LD3 + min(4 * st + g4, CW - 1)], acc[u], 0, 0, 0);
+            if (g4 < 2) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (wave + 4 * u < nt) {
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) {
+                            const int at = (4 * g4 + v) * LD2 + 16 * (wave + 4 * u) + m16;
+                            const float h = h2s[at];
+                            d2s[at] = acc[u][v] * (1.0f - h * h);
+                        }
                     }
-                }
-                const float h = h2s[r * LD2 + tid];
-                d2s[r * LD2 + tid] = s * (1.0f - h * h);
             }
         }
         __syncthreads();
         if (n_live > 0) {
             // 6a. delta1 of the own units, delta2 . w2[own, :]^T with the old w2, on the matrix
             // cores: K split over the waves, two tiles of 16 units
-#pragma unroll
-            for (int ib = 0; ib < HS; ib += 16) {
-                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            {
+                static_assert(kStepHS == 32, "two tiles of 16 units");
+                f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
                 const int kb = wave * kq + g4;
 #pragma unroll 4
-                for (int st = 0; st < kq; st += 4)
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(d2s[m16 * LD2 + kb + st], W2s[(ib + m16) * LD2 + kb + st], acc, 0, 0, 0);
+                for (int st = 0; st < kq; st += 4) {
+                    const float dv = d2s[m16 * LD2 + kb + st];
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(dv, W2s[m16 * LD2 + kb + st], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(dv, W2s[(16 + m16) * LD2 + kb + st], acc1, 0, 0, 0);
+                }
                 if (g4 < 2) {
 #pragma unroll
-                    for (int v = 0; v < 4; ++v) red[((size_t)wave * kStepRows + 4 * g4 + v) * HS + ib + m16] = acc[v];
+                    for (int v = 0; v < 4; ++v) {
+                        red[((size_t)wave * kStepRows + 4 * g4 + v) * HS + m16] = acc0[v];
+                        red[((size_t)wave * kStepRows + 4 * g4 + v) * HS + 16 + m16] = acc1[v];
+                    }
                 }
             }
-            // 6b. replicated output layer and b2 (thread = row k of w3)
+            // 6b. replicated output layer: dW3 = h2^T . delta3 on the matrix cores (rows of w3 x
+            // classes, K = the 8 rows); register v of lane (class m16, g4) is row 16 t + 4 g4 + v
+            for (int cb = 0; cb < CW; cb += 16) {
+                const int nt = H2 / 16;
+                float bf[kStepRows / 4];
+#pragma unroll
+                for (int st = 0; st < kStepRows / 4; ++st) bf[st] = d3s[(4 * st + g4) * LDD3 + cb + m16];
+                f32x4 acc[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int st = 0; st < kStepRows / 4; ++st)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(h2s[(4 * st + g4) * LD2 + 16 * min(wave + 4 * u, nt - 1) + m16], bf[st], acc[u], 0, 0, 0);
+                if (cb + m16 < C) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (wave + 4 * u < nt) {
+#pragma unroll
+                            for (int v = 0; v < 4; ++v) W3s[(16 * (wave + 4 * u) + 4 * g4 + v) * LD3 + cb + m16] -= scale * acc[u][v];
+                        }
+                }
+            }
             if (tid < H2) {
-                float hcol[kStepRows];
                 float g2 = 0.0f;
 #pragma unroll
-                for (int r = 0; r < kStepRows; ++r) { hcol[r] = h2s[r * LD2 + tid]; g2 += d2s[r * LD2 + tid]; }
-                float gw[32];
-#pragma unroll
-                for (int c = 0; c < 32; ++c) gw[c] = 0.0f;
-#pragma unroll
-                for (int r = 0; r < kStepRows; ++r)
-#pragma unroll
-                    for (int c = 0; c < 32; c += 4) {
-                        if (c < CW) {
-                            const float4 d = *reinterpret_cast<const float4*>(d3s + r * LDD3 + c);
-                            gw[c] += hcol[r] * d.x; gw[c + 1] += hcol[r] * d.y; gw[c + 2] += hcol[r] * d.z; gw[c + 3] += hcol[r] * d.w;
-                        }
-                    }
-#pragma unroll
-                for (int c = 0; c < 32; ++c)
-                    if (c < C) W3s[tid * LD3 + c] = w3r[c] - scale * gw[c];
+                for (int r = 0; r < kStepRows; ++r) g2 += d2s[r * LD2 + tid];
                 b2s[tid] -= scale * g2;
             }
             if (tid < C) {
@@ -407,7 +461,7 @@ __global__ __launch_bounds__(kStepThreads) void step_kernel(StepArgs a)
                 float g = 0.0f;
 #pragma unroll
                 for (int r = 0; r < kStepRows; ++r) g += xs[r * IN + j] * d1s[r * HS + i];
-                W1s[e] -= scale * g;
+                W1s[j * LDW1 + i] -= scale * g;
             }
             if (tid < HS) {
                 float g = 0.0f;
@@ -421,7 +475,7 @@ __global__ __launch_bounds__(kStepThreads) void step_kernel(StepArgs a)
 
     // write the owned parameters back; workgroup 0 also writes the replicated ones and the totals
     float* Pw = a.params;
-    for (int e = tid; e < IN * HS; e += kStepThreads) { const int j = e / HS, i = e - j * HS; Pw[(size_t)j * a.h1 + i0 + i] = W1s[e]; }
+    for (int e = tid; e < IN * HS; e += kStepThreads) { const int j = e / HS, i = e - j * HS; Pw[(size_t)j * a.h1 + i0 + i] = W1s[j * LDW1 + i]; }
     for (int e = tid; e < HS; e += kStepThreads) Pw[off_b1 + i0 + e] = b1s[e];
     for (int e = tid; e < HS * H2; e += kStepThreads) { const int i = e / H2, k = e - i * H2; Pw[off_w2 + (size_t)(i0 + i) * H2 + k] = W2s[i * LD2 + k]; }
     if (blk == 0) {
@@ -453,10 +507,10 @@ int net_pretrain_steps(Net* n, const float* d_win, uint32_t n_win, const uint32_
     struct Scratch { float* part = nullptr; unsigned* counter = nullptr; int* abort_flag = nullptr; };
     Scratch sc;
     const size_t part_bytes = 2ull * nb * kStepRows * n->h2 * sizeof(float);
-    SZ_HIP(hipMalloc((void**)&sc.part, part_bytes + 64));
+    SZ_HIP(hipMalloc((void**)&sc.part, part_bytes + 64 + 64 * sizeof(unsigned)));
     sc.counter = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(sc.part) + part_bytes);
-    sc.abort_flag = reinterpret_cast<int*>(sc.counter + 4);
-    hipError_t e = hipMemsetAsync(sc.counter, 0, 64, s);
+    sc.abort_flag = reinterpret_cast<int*>(sc.counter + 64);   // after the (at most 64) workgroup flags
+    hipError_t e = hipMemsetAsync(sc.counter, 0, 64 + 64 * sizeof(unsigned), s);
     StepArgs a{};
     a.params = n->d_params;
     a.in = (int)n->in; a.h1 = (int)n->h1; a.h2 = (int)n->h2; a.out = (int)n->out;
