@@ -155,6 +155,46 @@ def test_wide_net_config(sz, po, B):
     np.testing.assert_allclose(net.forward(x), onet.forward(x), atol=1e-4)
 
 
+@pytest.mark.parametrize("seed", [20240611, 7, 99])
+def test_random_shapes_match_oracle(sz, po, seed):
+    """A seeded sweep over layer widths, class counts and batch sizes: whichever kernels the
+    dispatch picks (matrix-core heads, vector head, GEMM fallback, 64- or 128-row tiles, padded
+    inputs, the resident step kernel), forward and one train_batch step stay within the bar."""
+    rng = np.random.default_rng(seed)
+    for case in range(24):
+        inp = int(rng.choice([60, 60, 60, 13, 64, 65, 100]))
+        h1 = int(rng.choice([32, 64, 96, 128, 160, 256, 512]))
+        h2 = int(rng.choice([16, 24, 32, 64, 128, 200, 256]))
+        C = int(rng.choice([1, 2, 5, 16, 17, 31, 32, 33, 64, 65, 100]))
+        B = int(rng.choice([1, 3, 8, 9, 63, 64, 65, 129, 700]))
+        dims = (inp, h1, h2, C)
+        onet = po.Net(*dims)
+        params = [rng.uniform(-0.5, 0.5, s).astype(np.float32) for s in onet.shapes()]
+        onet.set_params(params)
+        net = sz.SimpleNeuralNet(*dims, init=params)
+        x = rng.standard_normal((B, inp)).astype(np.float32)
+        x[rng.random(B) < 0.1] = 0.0  # some all-zero rows (train_batch still counts them, lib.rs:1002-1060)
+        msg = f"seed {seed} case {case}: dims {dims}, B {B}"
+        np.testing.assert_allclose(net.forward(x), onet.forward(x), atol=1e-4, err_msg=msg)
+        np.testing.assert_allclose(net.embed(x), onet.embed(x), atol=1e-4, err_msg=msg)
+        target = np.zeros(C, np.float32)
+        target[int(rng.integers(C))] = 1.0
+        net.train_batch(x, target, 0.02)
+        onet.train_batch(x, target, 0.02)
+        for p, q in zip(net.get_params(), onet.get_params()):
+            np.testing.assert_allclose(p, q, atol=2e-5, err_msg=msg)
+        if inp == 60:
+            perm = np.stack([rng.permutation(B) for _ in range(2)]).astype(np.uint32)
+            keep = (rng.random((2, B, 60)) >= 0.2).astype(np.uint8)
+            bs = int(rng.choice([1, 4, 8, 16]))
+            tc = int(rng.integers(C))
+            got = sz.pretrain_from_features(net, x, tc, C, 2, 0.01, 0.2, bs, perm=perm, keep=keep)
+            want = onet.pretrain_from_features(x, tc, C, 2, 0.01, 0.2, bs, perm=perm, keep=keep)
+            assert abs(got - want) <= 1e-4 * max(1.0, abs(want)), msg
+            for p, q in zip(net.get_params(), onet.get_params()):
+                np.testing.assert_allclose(p, q, atol=1e-4, err_msg=msg)
+
+
 @pytest.mark.parametrize("dims", [(100, 32, 16, 3), (64, 40, 24, 2), (7, 8, 4, 3), (63, 33, 17, 33)])
 def test_other_input_widths_match_oracle(sz, po, dims):
     # SimpleNeuralNet::new takes any sizes (lib.rs:767); the prepared rows are padded to a tile
