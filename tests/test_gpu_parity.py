@@ -76,6 +76,43 @@ def test_extract_batch_ragged_files(ext, oext):
             np.testing.assert_allclose(o, want, atol=1e-4)
 
 
+def _random_clip(rng, n):
+    kind = rng.integers(7)
+    t = np.arange(n, dtype=np.float64) / 44100.0
+    if kind == 0:
+        x = 0.3 * rng.standard_normal(n)
+    elif kind == 1:
+        x = 0.5 * np.sin(2 * np.pi * rng.uniform(50, 15000) * t) + 0.2 * np.sin(2 * np.pi * rng.uniform(50, 15000) * t)
+    elif kind == 2:
+        x = np.zeros(n)                                   # digital silence: both clamps
+    elif kind == 3:
+        x = np.sign(np.sin(2 * np.pi * rng.uniform(80, 400) * t)) * rng.uniform(0.1, 1.2)   # square wave, may clip
+    elif kind == 4:
+        x = np.zeros(n)
+        x[rng.integers(0, max(n, 1), size=max(n // 500, 1))] = rng.uniform(-1, 1)          # sparse impulses
+    elif kind == 5:
+        x = rng.uniform(-2, 2) / 32767.0 * rng.standard_normal(n)                          # a few LSBs of noise
+    else:
+        x = 0.25 * rng.standard_normal(n) + rng.uniform(-0.5, 0.5)                         # DC offset
+    return np.clip(np.round(x * 32767), -32768, 32767).astype(np.int16)
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_random_clips_match_oracle(ext, oext, seed):
+    """A seeded sweep over clip lengths (ragged, shorter than a window, exact multiples of the
+    hop) and signal kinds (noise, tones, silence, clipping squares, impulses, LSB noise, DC)."""
+    rng = np.random.default_rng(seed)
+    lens = [int(v) for v in rng.integers(0, 30000, size=14)] + [799, 800, 801, 1200, 1199, 400 * 20 + 800]
+    clips = [_random_clip(rng, n) for n in lens]
+    got = ext.extract_batch(clips)
+    for n, c, g in zip(lens, clips, got):
+        want = oext.extract(c, fft_mode=0)
+        assert g.shape == want.shape == (max(0, (n - 800) // 400 + 1) if n >= 800 else 0, 60)
+        if g.size:
+            np.testing.assert_allclose(g, want, atol=1e-4, err_msg=f"seed {seed}, {n} samples")
+            np.testing.assert_allclose(ext.extract(c), g, atol=0, rtol=0)  # one clip alone: identical
+
+
 def test_extract_long_clip_properties(ext, oext):
     # 60 s clip (6 614 windows): spot-check windows against the oracle and check the
     # size-independent properties of the z-score: zero mean, unit variance per frame
