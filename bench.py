@@ -186,7 +186,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # BENCH_FORCE_DIST=1 takes the multi-rank path with a single rank (rehearsal of the collective on one GPU)
+    multi = world > 1 or bool(os.environ.get("BENCH_FORCE_DIST"))
+    if multi:
         import torch.distributed as dist
         if args.backend == "nccl":
             torch.cuda.set_device(local_rank)
@@ -198,7 +200,7 @@ def main():
     else:
         dist = None
         torch.cuda.set_device(0)
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    dev = torch.device("cuda", local_rank if multi else 0)
     sz.lib().szh_init(dev.index)
 
     # ---- synthetic, device-resident inputs
@@ -215,7 +217,7 @@ def main():
     # RCCL reduces a torch-owned staging copy of the 0.67 MB vector (two device copies per step)
     # rather than library-owned memory it has never seen
     rdev = dev if args.backend == "nccl" else torch.device("cpu")  # gloo rehearsal reduces on the host
-    gstage = torch.empty(grad.shape, dtype=grad.dtype, device=rdev) if world > 1 else None
+    gstage = torch.empty(grad.shape, dtype=grad.dtype, device=rdev) if multi else None
     stream = torch.cuda.current_stream().cuda_stream
 
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
