@@ -140,6 +140,96 @@ __global__ void softmax_kernel(float* __restrict__ P, uint64_t rows, int C, int 
     }
 }
 
+// The same for wide outputs: one wavefront per row, lane j takes classes j, j + 64, ... (coalesced),
+// max and sum by wave reductions.  Rows are dealt to the waves of the grid round-robin.
+__device__ __forceinline__ float wave_max(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+constexpr int kSoftmaxWideMaxC = 1024;  // 16 classes per lane in registers
+__global__ __launch_bounds__(256) void softmax_wide_kernel(float* __restrict__ P, uint64_t rows, int C, int mode,
+                                                          const float* __restrict__ target,
+                                                          const int32_t* __restrict__ labels,
+                                                          const uint8_t* __restrict__ live, double* __restrict__ stats)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double loss_acc = 0.0, cnt_acc = 0.0;
+    for (uint64_t r = (uint64_t)blockIdx.x * 4 + wave; r < rows; r += (uint64_t)gridDim.x * 4) {
+        float* p = P + r * C;
+        float v[kSoftmaxWideMaxC / 64];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int q = 0; q < kSoftmaxWideMaxC / 64; ++q) {
+            const int j = lane + 64 * q;
+            v[q] = j < C ? p[j] : -INFINITY;
+            mx = fmaxf(mx, v[q]);
+        }
+        mx = wave_max(mx);
+        float sum = 0.0f;
+#pragma unroll
+        for (int q = 0; q < kSoftmaxWideMaxC / 64; ++q) {
+            v[q] = lane + 64 * q < C ? expf(v[q] - mx) : 0.0f;
+            sum += v[q];
+        }
+        sum = wave_sum(sum);
+        if (mode == 0) {
+#pragma unroll
+            for (int q = 0; q < kSoftmaxWideMaxC / 64; ++q)
+                if (lane + 64 * q < C) p[lane + 64 * q] = v[q] / sum;
+        } else {
+            const bool alive = live ? live[r] != 0 : true;
+            const int lab = labels ? labels[r] : -1;
+            float loss = 0.0f;
+#pragma unroll
+            for (int q = 0; q < kSoftmaxWideMaxC / 64; ++q) {
+                const int j = lane + 64 * q;
+                if (j < C) {
+                    const float o = v[q] / sum;
+                    const float t = labels ? (j == lab ? 1.0f : 0.0f) : target[j];
+                    if (t != 0.0f) loss -= t * logf(fmaxf(o, 1e-12f));
+                    p[j] = alive ? o - t : 0.0f;
+                }
+            }
+            loss = wave_sum(loss);
+            if (alive) { loss_acc += (double)loss; cnt_acc += 1.0; }
+        }
+    }
+    if (mode == 0) return;
+    __shared__ double s_loss[4], s_cnt[4];
+    if (lane == 0) { s_loss[wave] = loss_acc; s_cnt[wave] = cnt_acc; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double c = (s_cnt[0] + s_cnt[1]) + (s_cnt[2] + s_cnt[3]);
+        if (c > 0.0) {
+            atomicAdd(&stats[0], (s_loss[0] + s_loss[1]) + (s_loss[2] + s_loss[3]));
+            atomicAdd(&stats[1], c);
+        }
+    }
+}
+
+// softmax over the rows of P, by the kernel that suits the width
+static int launch_softmax(float* P, uint64_t rows, int C, int mode, const float* target, const int32_t* labels,
+                          const uint8_t* live, double* stats, hipStream_t s)
+{
+    if (C > 32 && C <= kSoftmaxWideMaxC) {
+        const unsigned blocks = (unsigned)std::min<uint64_t>((rows + 3) / 4, 256 * 16);
+        hipLaunchKernelGGL(softmax_wide_kernel, dim3(blocks), dim3(256), 0, s, P, rows, C, mode, target, labels, live, stats);
+    } else {
+        hipLaunchKernelGGL(softmax_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, P, rows, C, mode, target,
+                           labels, live, stats);
+    }
+    SZ_HIP(hipGetLastError());
+    return SZH_OK;
+}
+
 // Per-window vote of identify_speaker_list (lib.rs:1393-1401) on probability rows.
 __global__ void vote_kernel(const float* __restrict__ P, uint64_t rows, int C, float threshold,
                             unsigned long long* __restrict__ counts)
@@ -1014,8 +1104,15 @@ __global__ void colsum_kernel(const float* __restrict__ D, uint64_t rows, int co
     const uint64_t r0 = (uint64_t)blockIdx.y * rows_per_split;
     const uint64_t r1 = min(rows, r0 + (uint64_t)rows_per_split);
     float s = 0.0f;
-    if (c < cols)
-        for (uint64_t r = r0 + rg; r < r1; r += 4) s += D[r * ld + c];
+    if (c < cols) {
+        float s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;  // four independent chains keep four loads in flight
+        uint64_t r = r0 + rg;
+        for (; r + 12 < r1; r += 16) {
+            s += D[r * ld + c]; s1 += D[(r + 4) * ld + c]; s2 += D[(r + 8) * ld + c]; s3 += D[(r + 12) * ld + c];
+        }
+        for (; r < r1; r += 4) s += D[r * ld + c];
+        s = (s + s1) + (s2 + s3);
+    }
     part[rg][threadIdx.x & 63] = s;
     __syncthreads();
     if (rg == 0 && c < cols) {
@@ -1344,10 +1441,8 @@ int net_forward_dev(Net* n, const float* x_dev, uint64_t rows, float* out_dev, F
             if (n->out == 0) continue;
             rc = forward_logits(n, R, o, s);
             if (rc) return rc;
-            hipLaunchKernelGGL(softmax_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s, o, R, (int)n->out, 0,
-                               (const float*)nullptr, (const int32_t*)nullptr, (const uint8_t*)nullptr,
-                               (double*)nullptr);
-            SZ_HIP(hipGetLastError());
+            rc = launch_softmax(o, R, (int)n->out, 0, nullptr, nullptr, nullptr, nullptr, s);
+            if (rc) return rc;
         } else {
             SZ_HIP(hipMemcpyAsync(o, n->ws.h2, R * n->h2 * sizeof(float), hipMemcpyDeviceToDevice, s));
         }
@@ -1516,11 +1611,10 @@ int net_accumulate(Net* n, const AccumArgs& a, hipStream_t s)
             if (rc) return rc;
             {
                 ProfScope prof("softmax", s);
-                hipLaunchKernelGGL(softmax_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s, w.p, R,
-                                   (int)n->out, 1, a.target_dev, a.labels_dev ? a.labels_dev + r0 : nullptr,
-                                   (const uint8_t*)w.live, n->d_stats);
+                rc = launch_softmax(w.p, R, (int)n->out, 1, a.target_dev, a.labels_dev ? a.labels_dev + r0 : nullptr,
+                                    (const uint8_t*)w.live, n->d_stats, s);
             }
-            SZ_HIP(hipGetLastError());
+            if (rc) return rc;
             // delta2 = (delta3 . w3^T) * (1 - h2^2)
             GemmArgs g{};
             g.A = w.p; g.lda = n->out; g.B = P + n->off_w3(); g.ldb = n->out; g.C = w.d2; g.ldc = n->h2;
@@ -1711,10 +1805,8 @@ int net_vote_dev(Net* n, const float* x_dev, uint64_t rows, float threshold, uns
         }
         rc = forward_logits(n, R, n->ws.p, s);
         if (rc) return rc;
-        hipLaunchKernelGGL(softmax_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s, n->ws.p, R, (int)n->out,
-                           0, (const float*)nullptr, (const int32_t*)nullptr, (const uint8_t*)nullptr,
-                           (double*)nullptr);
-        SZ_HIP(hipGetLastError());
+        rc = launch_softmax(n->ws.p, R, (int)n->out, 0, nullptr, nullptr, nullptr, nullptr, s);
+        if (rc) return rc;
         if (counts_dev) {
             hipLaunchKernelGGL(vote_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), n->out * sizeof(unsigned int), s,
                                n->ws.p, R, (int)n->out, threshold, counts_dev);
