@@ -34,7 +34,7 @@ constexpr int kBaseThreads = 256;
 constexpr int kBaseWaves = kBaseThreads / 64;
 constexpr size_t kBaseLdsBytes = (size_t)kBaseWaves * kWinPerWave * kRegionStride * sizeof(float);
 
-__global__ __launch_bounds__(kBaseThreads, 2) void mfcc_base_kernel(const int16_t* __restrict__ pcm,
+__global__ __launch_bounds__(kBaseThreads, 3) void mfcc_base_kernel(const int16_t* __restrict__ pcm,
                                                                   const Segment* __restrict__ segs,
                                                                   uint32_t n_segs,
                                                                   const ExtractTables* __restrict__ T,
@@ -61,13 +61,28 @@ __global__ __launch_bounds__(kBaseThreads, 2) void mfcc_base_kernel(const int16_
             // (The opaque value is an offset, not the pointer, so the loads stay global_load.)
             uint32_t opaque0 = 0;
             asm volatile("" : "+s"(opaque0));
-            phase1(u, win, R, T + opaque0);
+            {
+                v2f x0[20];
+                {
+                    v2f hi_a[kHalfRows], hi_b[kHalfRows];
+                    phase1(u, win, R, T + opaque0, hi_a, hi_b);
+                    wave_sync();
+                    read_row(R, first_row(u), x0);
+                    wave_sync();
+                    phase1_high(u, R, hi_a, hi_b);
+                }
+                wave_sync();
+                asm volatile("" : "+s"(opaque0));
+                phase2(u, R, T + opaque0, x0);
+            }
             wave_sync();
-            asm volatile("" : "+s"(opaque0));
-            phase2(u, R, T + opaque0);
-            wave_sync();
-            asm volatile("" : "+s"(opaque0));
-            phase3(u, R, T + opaque0);
+            {
+                float p[kMelSteps];
+                phase3_load(u, R, p);
+                wave_sync();
+                asm volatile("" : "+s"(opaque0));
+                phase3_sweep(u, R, T + opaque0, p);
+            }
             wave_sync();
             phase4(u, R, T + opaque0);
             wave_sync();
@@ -344,7 +359,7 @@ int plan_run(Plan* p, const int16_t* pcm_dev, float* feats_dev, hipStream_t stre
     }
     if (int rc = allow_dynamic_lds((const void*)mfcc_base_kernel, kBaseLdsBytes)) return rc;
     const uint32_t wave_jobs = (p->n_segs + kBaseWaves - 1) / kBaseWaves;
-    const uint32_t grid_a = wave_jobs < 256u * 2u * 8u ? wave_jobs : 256u * 2u * 8u;
+    const uint32_t grid_a = wave_jobs < 256u * 3u * 8u ? wave_jobs : 256u * 3u * 8u;
     {
         ProfScope prof("mfcc_base", stream);
         hipLaunchKernelGGL(mfcc_base_kernel, dim3(grid_a), dim3(kBaseThreads), kBaseLdsBytes, stream, pcm_dev,

@@ -5,12 +5,15 @@
 // CPU lane emulator of the unit tests), so running every lane of a group through phase N
 // before any lane starts phase N+1 is exactly what a wavefront does.
 //
-// Scratch region R, in floats (kRegionFloats per window):
-//   [0, 800)    Y[k1][n2] complex, row stride 40 floats       (phase 1 -> phase 2)
-//   [0, 410)    power spectrum, bin k at pslot(k)             (phase 2 -> phase 3; aliases Y)
-//   [412, 742)  mel partial sums, (fall, rise) pairs, lane q at 412 + 33 q (an odd stride, so
-//               that the ten lanes hit different LDS banks)   (phase 3 -> phase 4)
-//   [744, 770)  log mel energies                              (phase 4 -> phase 5)
+// Scratch region R, in floats (kRegionFloats per window).  Everything aliases: a lane reads all it
+// needs from one layout into registers before any lane writes the next one (on the device the
+// LDS operations of a wavefront execute in program order; the emulator copies the region).
+//   [0, 400)    ten rows of Y[k1][n2] complex, row stride 40 floats: rows k1 = 0..9 first, and,
+//               once every lane holds its row of those, rows 10..19       (phase 1 -> phase 2)
+//   [0, 410)    power spectrum, bin k at pslot(k)                           (phase 2 -> phase 3)
+//   [0, 330)    mel partial sums, (fall, rise) pairs, lane q at 33 q (an odd stride, so that
+//               the ten lanes hit different LDS banks)                      (phase 3 -> phase 4)
+//   [332, 358)  log mel energies                                            (phase 4 -> phase 5)
 // On the device consecutive windows' regions start kRegionStride floats apart, which shifts
 // each window by 4 banks against its neighbour.
 #pragma once
@@ -22,12 +25,14 @@
 
 namespace sz {
 
-constexpr int kRegionFloats = 800;
-constexpr int kRegionStride = 804;
+constexpr int kRegionFloats = 412;
+constexpr int kRegionStride = 420;
 constexpr int kRowFloats = 40;
-constexpr int kPartOff = 412;
-constexpr int kLogOff = 744;
+constexpr int kHalfRows = 10;      // rows of Y exchanged at a time
+constexpr int kPartOff = 0;
+constexpr int kLogOff = 332;
 static_assert(kPartOff + kGroup * kPairStride <= kLogOff && kLogOff + kMels <= kRegionFloats, "region layout");
+static_assert(kHalfRows * kRowFloats <= kRegionFloats && pslot(kBins - 1) < kRegionFloats, "region layout");
 
 struct alignas(8) pcm4 { int16_t s[4]; };
 struct alignas(16) f4 { float v[4]; };
@@ -41,10 +46,11 @@ struct alignas(16) f4 { float v[4]; };
 SZ_HD float lo16(uint32_t w) { return (float)(int16_t)(w & 0xffffu); }
 SZ_HD float hi16(uint32_t w) { return (float)(int16_t)(w >> 16); }
 
-// Phase 1: load this lane's samples of the window, two 20-point DFTs over n1, twiddle, store Y.
+// Phase 1: load this lane's samples of the window, two 20-point DFTs over n1, twiddle; rows
+// k1 < 10 of Y go to R, rows 10..19 stay in hi_a / hi_b until phase1_high stores them.
 // win points at the first sample of the window and must be 8-byte aligned.  The two columns
 // are transformed one after the other so that only one 20-point DFT is live in registers.
-SZ_HD void phase1(int u, const int16_t* win, float* R, const ExtractTables* T)
+SZ_HD void phase1(int u, const int16_t* win, float* R, const ExtractTables* T, v2f (&hi_a)[kHalfRows], v2f (&hi_b)[kHalfRows])
 {
     uint32_t ra[20], rb[20];
 #pragma unroll
@@ -61,7 +67,8 @@ SZ_HD void phase1(int u, const int16_t* win, float* R, const ExtractTables* T)
 #pragma unroll
         for (int k1 = 0; k1 < 20; ++k1) {
             const v2f y = cmul(A[k1], mk(T->twa[k1][u][0], T->twa[k1][u][1]));
-            *reinterpret_cast<v2f*>(R + k1 * kRowFloats + 4 * u) = y;
+            if (k1 < kHalfRows) *reinterpret_cast<v2f*>(R + k1 * kRowFloats + 4 * u) = y;
+            else hi_a[k1 - kHalfRows] = y;
         }
     }
     SZ_SCHED_FENCE();
@@ -73,10 +80,26 @@ SZ_HD void phase1(int u, const int16_t* win, float* R, const ExtractTables* T)
 #pragma unroll
         for (int k1 = 0; k1 < 20; ++k1) {
             const v2f y = cmul(B[k1], mk(T->twb[k1][u][0], T->twb[k1][u][1]));
-            *reinterpret_cast<v2f*>(R + k1 * kRowFloats + 4 * u + 2) = y;
+            if (k1 < kHalfRows) *reinterpret_cast<v2f*>(R + k1 * kRowFloats + 4 * u + 2) = y;
+            else hi_b[k1 - kHalfRows] = y;
         }
     }
 }
+
+// Rows 10..19 of Y replace rows 0..9 once every lane has read its row of those.
+SZ_HD void phase1_high(int u, float* R, const v2f (&hi_a)[kHalfRows], const v2f (&hi_b)[kHalfRows])
+{
+#pragma unroll
+    for (int k = 0; k < kHalfRows; ++k) {
+        *reinterpret_cast<v2f*>(R + k * kRowFloats + 4 * u) = hi_a[k];
+        *reinterpret_cast<v2f*>(R + k * kRowFloats + 4 * u + 2) = hi_b[k];
+    }
+}
+
+// the row of the first half that lane u transforms in phase 2: row u (rows 0 and 10 for lane 0)
+SZ_HD int first_row(int u) { return u; }
+// its row of the second half, as an index into the stored rows 10..19
+SZ_HD int second_row(int u) { return u == 0 ? 0 : kHalfRows - u; }
 
 SZ_HD void read_row(const float* R, int row, v2f (&x)[20])
 {
@@ -100,14 +123,15 @@ SZ_HD void split_pair(v2f P, v2f Q, v2f w, float& pk, float& pn)
     pn = Xn[0] * Xn[0] + Xn[1] * Xn[1];
 }
 
-// Phase 2: two 20-point DFTs over n2, real-FFT split, power spectrum into R[0..400].
-SZ_HD void phase2(int u, float* R, const ExtractTables* T)
+// Phase 2: two 20-point DFTs over n2 (x0 = this lane's row of the first half, read before rows
+// 10..19 were stored; its row of the second half is read here), real-FFT split, power spectrum
+// into R[0..410].
+SZ_HD void phase2(int u, float* R, const ExtractTables* T, const v2f (&x0)[20])
 {
     const bool z = (u == 0);
     v2f x[20], ZA[20], ZB[20];
-    read_row(R, z ? 0 : u, x);
-    dft20(x, ZA);
-    read_row(R, z ? 10 : 20 - u, x);
+    dft20(x0, ZA);
+    read_row(R, second_row(u), x);
     dft20(x, ZB);
 #pragma unroll
     for (int s = 0; s < kSplitSlots; ++s) {
@@ -133,19 +157,24 @@ SZ_HD void phase2(int u, float* R, const ExtractTables* T)
     }
 }
 
-// Phase 3: this lane's 40 bins of the mel sweep.  Fully unrolled: the 40 weight pairs and the
-// 40 power values are requested up front, the flush points come from a per-lane bit mask.
-SZ_HD void phase3(int q, float* R, const ExtractTables* T)
+// Phase 3: this lane's 40 bins of the mel sweep, fully unrolled.  phase3_load takes the lane's 40
+// power values into registers; phase3_sweep, which overwrites the power spectrum with the partial
+// sums, runs once every lane has done that.  The flush points come from a per-lane bit mask.
+SZ_HD void phase3_load(int q, const float* R, float (&p)[kMelSteps])
+{
+#pragma unroll
+    for (int st = 0; st < kMelSteps; ++st) p[st] = R[(kMelSteps + 1) * q + 1 + st];  // pslot(40 q + 1 + st)
+}
+
+SZ_HD void phase3_sweep(int q, float* R, const ExtractTables* T, const float (&p)[kMelSteps])
 {
     const uint64_t flush = T->mel_flush[q];
-    float wf[kMelSteps], wr[kMelSteps], p[kMelSteps];
+    float wf[kMelSteps], wr[kMelSteps];
 #pragma unroll
     for (int st = 0; st < kMelSteps; ++st) {
         wf[st] = T->melw[st][q][0];
         wr[st] = T->melw[st][q][1];
     }
-#pragma unroll
-    for (int st = 0; st < kMelSteps; ++st) p[st] = R[(kMelSteps + 1) * q + 1 + st];  // pslot(40 q + 1 + st)
     float af = 0.0f, ar = 0.0f;
     float* out = R + kPartOff + q * kPairStride;
     if (q == 0) out[kZeroSlot] = 0.0f;  // what the unused recombination entries point at

@@ -30,10 +30,15 @@ int main(int argc, char** argv)
         if (q < -32768) q = -32768;
         pcm[i] = (int16_t)q;
     }
+    // A wavefront runs every lane through one instruction before the next; the region's layouts
+    // alias, so each step below lets all ten lanes read before any of them writes.
     alignas(16) float R[kRegionFloats];
-    for (int u = 0; u < kGroup; ++u) phase1(u, pcm, R, &T);
-    // phase 2 reads every row before any lane writes the aliased power spectrum: emulate
-    // the wavefront by letting each lane work on a private copy of Y and merging the writes
+    static v2f hi_a[kGroup][kHalfRows], hi_b[kGroup][kHalfRows], x0[kGroup][20];
+    for (int u = 0; u < kGroup; ++u) phase1(u, pcm, R, &T, hi_a[u], hi_b[u]);   // rows 0..9 of Y
+    for (int u = 0; u < kGroup; ++u) read_row(R, first_row(u), x0[u]);
+    for (int u = 0; u < kGroup; ++u) phase1_high(u, R, hi_a[u], hi_b[u]);       // rows 10..19 replace them
+    // phase 2 reads its second row before any lane writes the aliased power spectrum: each lane
+    // works on a private copy of Y and the writes are merged
     alignas(16) float Y[kRegionFloats];
     for (int i = 0; i < kRegionFloats; ++i) Y[i] = R[i];
     alignas(16) float Pm[kRegionFloats];
@@ -41,7 +46,7 @@ int main(int argc, char** argv)
     for (int u = 0; u < kGroup; ++u) {
         alignas(16) float tmp[kRegionFloats];
         for (int i = 0; i < kRegionFloats; ++i) tmp[i] = Y[i];
-        phase2(u, tmp, &T);
+        phase2(u, tmp, &T, x0[u]);
         // collect the bins this lane owns from the tables
         for (int s = 0; s < kSplitSlots; ++s) {
             if (s == 20 && u != 0) continue;
@@ -73,7 +78,9 @@ int main(int argc, char** argv)
         double e = std::fabs((double)R[pslot(k)] - pw[k]) / pmax;
         if (e > e_pow) e_pow = e;
     }
-    for (int q = 0; q < kGroup; ++q) phase3(q, R, &T);
+    static float pw40[kGroup][kMelSteps];
+    for (int q = 0; q < kGroup; ++q) phase3_load(q, R, pw40[q]);
+    for (int q = 0; q < kGroup; ++q) phase3_sweep(q, R, &T, pw40[q]);   // partial sums overwrite the power spectrum
     for (int q = 0; q < kGroup; ++q) phase4(q, R, &T);
     double e_log = 0, e_mfcc = 0;
     std::vector<double> lm(kMels);
