@@ -1202,15 +1202,23 @@ __global__ void apply_kernel(float* __restrict__ params, const float* __restrict
 }
 
 // Rows per launch.  Large enough that a launch is many rounds of workgroups per CU, so that the
-// prologues and epilogues of some overlap the matrix work of others (measured: 49 152 rows,
-// one round, is 15 % slower per row); 393 216 rows need about 2.5 GB of workspace for the
-// 60-512-256 network.
-static const uint64_t kChunkRows = [] {
+// prologues and epilogues of some overlap the matrix work of others, and that the fixed cost of the
+// ~7 launches per chunk is small (measured at 60-512-256: 49 152 rows, one round, is 15 % slower
+// per row; 393 216 -> 1 572 864 rows gains another 3 %).  The chunk is sized so that the
+// workspace, which holds every activation and delta of a chunk, stays near 10 GB.
+static const uint64_t kChunkRowsEnv = [] {
     // STREAMZ_CHUNK_ROWS overrides the rows per launch (a tuning knob; at least 256, multiple of 128)
     const char* e = std::getenv("STREAMZ_CHUNK_ROWS");
     const uint64_t v = e ? std::strtoull(e, nullptr, 10) : 0;
-    return v >= 256 ? (v + 127) / 128 * 128 : (uint64_t)393216;
+    return v >= 256 ? (v + 127) / 128 * 128 : (uint64_t)0;
 }();
+static uint64_t chunk_rows(const Net* n)
+{
+    if (kChunkRowsEnv) return kChunkRowsEnv;
+    const uint64_t per_row = 4ull * (64 + n->in + 2ull * n->h1 + 2ull * n->h2 + n->out);
+    const uint64_t r = (10ull << 30) / per_row;
+    return std::min<uint64_t>(std::max<uint64_t>(r, 131072), 1572864) / 128 * 128;
+}
 // Most split-K slabs of a weight-gradient product: enough that tiles x splits is several
 // workgroups per CU (dW1 has only 4 column tiles, dW2 has 8 tiles)
 constexpr uint64_t kMaxSplits = 64, kMaxSplitsW1 = 256;
@@ -1218,7 +1226,7 @@ constexpr uint64_t kMaxSplits = 64, kMaxSplitsW1 = 256;
 int ensure_workspace(Net* n, uint64_t rows)
 {
     Workspace& w = n->ws;
-    if (rows > kChunkRows) rows = kChunkRows;
+    if (rows > chunk_rows(n)) rows = chunk_rows(n);
     if (w.rows >= rows && w.out == n->out) return SZH_OK;
     float** ptrs[] = {&w.xd, &w.h1, &w.h2, &w.p, &w.d2, &w.d1, &w.slab, &w.w2t};
     for (float** p : ptrs) { if (*p) (void)hipFree(*p); *p = nullptr; }
@@ -1432,8 +1440,8 @@ int net_forward_dev(Net* n, const float* x_dev, uint64_t rows, float* out_dev, F
     int rc = ensure_workspace(n, rows);
     if (rc) return rc;
     const uint32_t ow = kind == kFwdProbs ? n->out : n->h2;
-    for (uint64_t r0 = 0; r0 < rows; r0 += kChunkRows) {
-        const uint64_t R = std::min<uint64_t>(kChunkRows, rows - r0);
+    for (uint64_t r0 = 0; r0 < rows; r0 += chunk_rows(n)) {
+        const uint64_t R = std::min<uint64_t>(chunk_rows(n), rows - r0);
         rc = forward_hidden(n, x_dev + r0 * n->in, R, kind == kFwdEmbedRelu, s);
         if (rc) return rc;
         float* o = out_dev + r0 * ow;
@@ -1520,7 +1528,7 @@ int net_accumulate(Net* n, const AccumArgs& a, hipStream_t s)
     float* w3tab = w.w2t + (uint64_t)n->h1 * n->h2;  // behind the transposed w2 (a multiple of 4 floats in)
     // Every chunk adds its split-K partials into the same slabs (the first one overwrites them);
     // the slabs are folded into the gradient vector once, after the last chunk.
-    const uint64_t rows0 = std::min<uint64_t>(kChunkRows, a.rows);
+    const uint64_t rows0 = std::min<uint64_t>(chunk_rows(n), a.rows);
     const SplitPlan sp = plan_splits(rows0, (int)kMaxSplits);
     const SplitPlan sp1 = plan_splits(rows0, (int)kMaxSplitsW1);
     // the output layer: matrix-core head with dW3 in registers (<= 16 classes), matrix-core head
@@ -1548,8 +1556,8 @@ int net_accumulate(Net* n, const AccumArgs& a, hipStream_t s)
         head_tpb = (tiles + head_blocks - 1) / head_blocks;
         head_blocks = (tiles + head_tpb - 1) / head_tpb;
     }
-    for (uint64_t r0 = 0; r0 < a.rows; r0 += kChunkRows) {
-        const uint64_t R = std::min<uint64_t>(kChunkRows, a.rows - r0);
+    for (uint64_t r0 = 0; r0 < a.rows; r0 += chunk_rows(n)) {
+        const uint64_t R = std::min<uint64_t>(chunk_rows(n), a.rows - r0);
         const bool add = r0 != 0;
         // gather / dropout / live flags
         {
@@ -1786,8 +1794,8 @@ int net_vote_dev(Net* n, const float* x_dev, uint64_t rows, float threshold, uns
     if (rows == 0 || n->out == 0) return SZH_OK;
     int rc = ensure_workspace(n, rows);
     if (rc) return rc;
-    for (uint64_t r0 = 0; r0 < rows; r0 += kChunkRows) {
-        const uint64_t R = std::min<uint64_t>(kChunkRows, rows - r0);
+    for (uint64_t r0 = 0; r0 < rows; r0 += chunk_rows(n)) {
+        const uint64_t R = std::min<uint64_t>(chunk_rows(n), rows - r0);
         rc = forward_hidden(n, x_dev + r0 * n->in, R, false, s);
         if (rc) return rc;
         const int ncb = ((int)n->out + 15) / 16;
