@@ -40,7 +40,7 @@ int launch_gemm(GemmArgs g, int splits, hipStream_t s)
     ProfScope prof(kGemmTagName[TAG], s);
     // 64-row tiles when 128-row tiles would leave compute units without a workgroup
     const long tiles128 = (long)((g.N + BN - 1) / BN) * ((g.M + BM - 1) / BM) * splits;
-    if (g.M <= 64 || tiles128 < 256) {
+    if (g.M <= 64 || (splits == 1 && tiles128 < 256)) {
         dim3 grid((g.N + BN - 1) / BN, (g.M + 63) / 64, splits);
         hipLaunchKernelGGL((gemm_kernel<AM, BMd, EPI, TAG, 64, kGemmKT, kGemmDB>), grid, dim3(kGemmThreads), 0, s, g);
     } else {
@@ -1528,7 +1528,11 @@ int net_accumulate(Net* n, const AccumArgs& a, hipStream_t s)
     float* w3tab = w.w2t + (uint64_t)n->h1 * n->h2;  // behind the transposed w2 (a multiple of 4 floats in)
     // Every chunk adds its split-K partials into the same slabs (the first one overwrites them);
     // the slabs are folded into the gradient vector once, after the last chunk.
-    const uint64_t rows0 = std::min<uint64_t>(chunk_rows(n), a.rows);
+    // Chunks of equal size (a short last chunk would run its split-K products on a fraction of the
+    // K ranges the first chunk fixed).
+    const uint64_t n_chunks = (a.rows + chunk_rows(n) - 1) / chunk_rows(n);
+    const uint64_t chunk = ((a.rows + n_chunks - 1) / n_chunks + 127) / 128 * 128;
+    const uint64_t rows0 = std::min<uint64_t>(chunk, a.rows);
     const SplitPlan sp = plan_splits(rows0, (int)kMaxSplits);
     const SplitPlan sp1 = plan_splits(rows0, (int)kMaxSplitsW1);
     // the output layer: matrix-core head with dW3 in registers (<= 16 classes), matrix-core head
@@ -1556,8 +1560,8 @@ int net_accumulate(Net* n, const AccumArgs& a, hipStream_t s)
         head_tpb = (tiles + head_blocks - 1) / head_blocks;
         head_blocks = (tiles + head_tpb - 1) / head_tpb;
     }
-    for (uint64_t r0 = 0; r0 < a.rows; r0 += chunk_rows(n)) {
-        const uint64_t R = std::min<uint64_t>(chunk_rows(n), a.rows - r0);
+    for (uint64_t r0 = 0; r0 < a.rows; r0 += chunk) {
+        const uint64_t R = std::min<uint64_t>(chunk, a.rows - r0);
         const bool add = r0 != 0;
         // gather / dropout / live flags
         {
