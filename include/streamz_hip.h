@@ -51,6 +51,9 @@ typedef struct szh_net szh_net;
 
 /* Select the HIP device this thread's later calls use (ordinal as in hipSetDevice). */
 int szh_init(int device_ordinal);
+/* Wait for everything this process has enqueued on the current device (call before exit or before
+ * handing the device to another library; handles stay valid and are destroyed by their own calls). */
+int szh_shutdown(void);
 const char *szh_last_error(void);
 /* free() for buffers this library returned (szh_load_cached_features, szh_wav_read). */
 void szh_free(void *p);

@@ -27,6 +27,7 @@ def library_path():
 _SIGS = {
     # name: (restype, argtypes)
     "szh_init": (C.c_int, [C.c_int]),
+    "szh_shutdown": (C.c_int, []),
     "szh_last_error": (C.c_char_p, []),
     "szh_free": (None, [C.c_void_p]),
     "szh_window_count": (C.c_uint64, [C.c_uint64]),

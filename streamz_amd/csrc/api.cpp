@@ -449,6 +449,13 @@ int szh_init(int device_ordinal)
     return SZH_OK;
 }
 
+int szh_shutdown(void)
+{
+    // handles own all device memory; what is left is work still in flight on the device
+    SZ_HIP(hipDeviceSynchronize());
+    return SZH_OK;
+}
+
 const char* szh_last_error(void) { return g_err; }
 void szh_free(void* p) { std::free(p); }
 
