@@ -436,32 +436,49 @@ __global__ __launch_bounds__(kStepThreads) void step_kernel(StepArgs a)
                                 (red[(2 * kStepRows + r) * HS + i] + red[(3 * kStepRows + r) * HS + i]);
                 d1s[r * HS + i] = h1s[i * kStepRows + r] > 0.0f ? s : 0.0f;
             }
-            // 6c. own rows of w2: all reads of the column first, then the writes
-            if (tid < H2) {
-                float d[kStepRows], wv[kStepHS];
+            // 6c. own rows of w2 -= scale * h1^T . delta2 on the matrix cores (units x columns, K = the
+            // 8 rows); register v of lane (column m16, g4) is unit 16 ib + 4 g4 + v
+            {
+                float af[2][kStepRows / 4];  // h1[row 4 st + g4][unit 16 ib + m16]
 #pragma unroll
-                for (int r = 0; r < kStepRows; ++r) d[r] = d2s[r * LD2 + tid];
+                for (int ib = 0; ib < 2; ++ib)
 #pragma unroll
-                for (int i = 0; i < HS; ++i) wv[i] = W2s[i * LD2 + tid];
+                    for (int st = 0; st < kStepRows / 4; ++st) af[ib][st] = h1s[(16 * ib + m16) * kStepRows + 4 * st + g4];
+                for (int t = wave; t < H2 / 16; t += 4) {
+                    const float b0 = d2s[g4 * LD2 + 16 * t + m16], b1 = d2s[(4 + g4) * LD2 + 16 * t + m16];
 #pragma unroll
-                for (int i = 0; i < HS; ++i) {
-                    const float4 ha = *reinterpret_cast<const float4*>(h1s + i * kStepRows);
-                    const float4 hb = *reinterpret_cast<const float4*>(h1s + i * kStepRows + 4);
-                    const float g = ha.x * d[0] + ha.y * d[1] + ha.z * d[2] + ha.w * d[3] + hb.x * d[4] + hb.y * d[5] +
-                                    hb.z * d[6] + hb.w * d[7];
-                    wv[i] -= scale * g;
+                    for (int ib = 0; ib < 2; ++ib) {
+                        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[ib][0], b0, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[ib][1], b1, acc, 0, 0, 0);
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) W2s[(16 * ib + 4 * g4 + v) * LD2 + 16 * t + m16] -= scale * acc[v];
+                    }
                 }
-#pragma unroll
-                for (int i = 0; i < HS; ++i) W2s[i * LD2 + tid] = wv[i];
             }
             __syncthreads();
-            // own columns of w1, own b1
-            for (int e = tid; e < IN * HS; e += kStepThreads) {
-                const int j = e / HS, i = e - j * HS;
-                float g = 0.0f;
+            // own columns of w1 -= scale * x^T . delta1 (inputs x units, K = the 8 rows), own b1
+            {
+                float bf[2][kStepRows / 4];  // delta1[row 4 st + g4][unit 16 ib + m16]
 #pragma unroll
-                for (int r = 0; r < kStepRows; ++r) g += xs[r * IN + j] * d1s[r * HS + i];
-                W1s[j * LDW1 + i] -= scale * g;
+                for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+                    for (int st = 0; st < kStepRows / 4; ++st) bf[ib][st] = d1s[(4 * st + g4) * HS + 16 * ib + m16];
+                for (int tj = wave; tj < (IN + 15) / 16; tj += 4) {
+                    const int j = 16 * tj + m16;
+                    const float a0 = j < IN ? xs[g4 * IN + j] : 0.0f, a1 = j < IN ? xs[(4 + g4) * IN + j] : 0.0f;
+#pragma unroll
+                    for (int ib = 0; ib < 2; ++ib) {
+                        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bf[ib][0], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bf[ib][1], acc, 0, 0, 0);
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) {
+                            const int jj = 16 * tj + 4 * g4 + v;
+                            if (jj < IN) W1s[jj * LDW1 + 16 * ib + m16] -= scale * acc[v];
+                        }
+                    }
+                }
             }
             if (tid < HS) {
                 float g = 0.0f;
