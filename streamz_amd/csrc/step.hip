@@ -55,16 +55,20 @@ struct StepArgs {
     double* totals;          // += {loss, live rows}
 };
 
-// All workgroups arrive, then all leave.  Workgroup b publishes the number of barriers it has
+// All workgroups arrive (barrier_arrive), then all leave (barrier_wait).  Workgroup b publishes the number of barriers it has
 // reached in flags[b] (a plain release store: no read-modify-write that would queue up behind the
 // other workgroups' at one address); one lane per workgroup then waits for that workgroup's flag.
-__device__ bool grid_barrier(unsigned* flags, int n_blocks, unsigned arrived, int* abort_flag)
+__device__ void barrier_arrive(unsigned* flags, unsigned arrived)
 {
-    __shared__ int ok;
     __threadfence();   // this thread's global writes are visible device-wide
-    if (threadIdx.x == 0) ok = 1;
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_store(&flags[blockIdx.x], arrived, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ bool barrier_wait(unsigned* flags, int n_blocks, unsigned arrived, int* abort_flag)
+{
+    __shared__ int ok;
+    if (threadIdx.x == 0) ok = 1;
+    __syncthreads();
     if ((int)threadIdx.x < n_blocks) {
         unsigned spins = 0;
         while (__hip_atomic_load(&flags[threadIdx.x], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < arrived) {
@@ -202,7 +206,6 @@ __global__ __launch_bounds__(kStepThreads) void step_kernel(StepArgs a)
             }
         }
         __syncthreads();
-        if (step + 1 < n_steps) load_x(step + 1, xv);  // in flight during the rest of the step
         if (tid == 0) {
             int n = 0;
             for (int r = 0; r < kStepRows; ++r) n += live_s[r];
@@ -262,7 +265,10 @@ __global__ __launch_bounds__(kStepThreads) void step_kernel(StepArgs a)
             }
         }
         // 4. everybody's partials are out
-        healthy = grid_barrier(a.counter, NB, (unsigned)(step + 1), a.abort_flag);
+        barrier_arrive(a.counter, (unsigned)(step + 1));
+        // the next step's inputs (index arithmetic, dropout draws, loads) while the others arrive
+        if (step + 1 < n_steps) load_x(step + 1, xv);
+        healthy = barrier_wait(a.counter, NB, (unsigned)(step + 1), a.abort_flag);
         if (!healthy) break;
         // 5a. h2 = tanh(b2 + sum of the partials).  Wave w sums workgroups w, w+4, ... with 16-byte
         // loads (4 columns per lane), all issued before the first add; the four waves' sums are
