@@ -305,6 +305,9 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_kernel(GemmArgs g)
                         acc[0][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[j], fbn[cur][tn], acc[0][tn], 0, 0, 0);
                         acc[1][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[j], fbn[cur][tn], acc[1][tn], 0, 0, 0);
                     }
+                    // keep the LDS reads of the next step between the MFMA groups instead of ahead of them
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2 * TN, 0);  // MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x100, TN, 0);      // DS read
                 }
                 a0 = n0; a1 = n1;
             }
