@@ -328,6 +328,8 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_kernel(GemmArgs g)
                     acc[0][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[cur], fbn[cur][tn], acc[0][tn], 0, 0, 0);
                     acc[1][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[cur], fbn[cur][tn], acc[1][tn], 0, 0, 0);
                 }
+                __builtin_amdgcn_sched_group_barrier(0x008, 2 * TN, 0);  // MFMA
+                __builtin_amdgcn_sched_group_barrier(0x100, TN + 2, 0);  // DS read
             }
         }
         if (DB) {
