@@ -95,6 +95,20 @@ int szh_plan_window_offsets(const szh_plan *plan, uint64_t *out);
  * no host copy, no synchronisation. */
 int szh_plan_run_dev(szh_plan *plan, const int16_t *pcm_dev, float *feats_dev, void *stream);
 
+/* No counterpart in the reference: szh_plan_run_dev for ONE clip, for callers that cannot
+ * allocate (code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).
+ * It allocates nothing, on the host or on the device: the segment tables and the per-window
+ * MFCCs that a plan keeps in its own allocations live in a fixed 1.4 MB device array that every
+ * GPU the library runs on holds until the process ends.  pcm_dev: n_samples mono samples starting
+ * at a 16-byte aligned device address; feats_dev: szh_window_count(n_samples) * 60 floats.  At
+ * most SZH_NOALLOC_MAX_WINDOWS windows (about 148 s of audio), else SZH_EINVAL.  Only enqueues
+ * work on `stream`.  All calls on one GPU share the array: calls that overlap on one GPU (two
+ * streams or two threads) race; calls on one stream are safe back to back.  szh_init on the
+ * device does the one-time set-up; without it the first call on a device does. */
+#define SZH_NOALLOC_MAX_WINDOWS 16384
+int szh_extract_dev_noalloc(szh_extractor *ext, const int16_t *pcm_dev, uint64_t n_samples, float *feats_dev,
+                            void *stream);
+
 /* ---- SimpleNeuralNet ---------------------------------------------------------------- */
 
 /* SimpleNeuralNet::new(input, hidden1, hidden2, output), lib.rs:767-790.

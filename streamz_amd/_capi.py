@@ -41,6 +41,7 @@ _SIGS = {
     "szh_plan_total_windows": (C.c_uint64, [C.c_void_p]),
     "szh_plan_window_offsets": (C.c_int, [C.c_void_p, C.c_void_p]),
     "szh_plan_run_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "szh_extract_dev_noalloc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
     "szh_net_create": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint64,
                                  C.POINTER(C.c_void_p)]),
     "szh_net_destroy": (None, [C.c_void_p]),
@@ -166,6 +167,11 @@ class FeatureExtractor:
         _check(lib().szh_extract(self._h, _p(pcm), pcm.size, _p(out), cap, C.byref(n)))
         assert n.value == cap
         return out
+
+    def extract_dev_noalloc(self, pcm_ptr, n_samples, feats_ptr, stream=0):
+        """One clip at a device address, through the entry point that allocates nothing."""
+        _check(lib().szh_extract_dev_noalloc(self._h, C.c_void_p(pcm_ptr), n_samples, C.c_void_p(feats_ptr),
+                                             C.c_void_p(stream)))
 
     def extract_batch(self, clips):
         clips = [np.ascontiguousarray(c, np.int16) for c in clips]

@@ -446,7 +446,7 @@ int szh_init(int device_ordinal)
     if (e != hipSuccess || n == 0) { set_error("no HIP device available"); return SZH_ENODEVICE; }
     if (device_ordinal < 0 || device_ordinal >= n) { set_error("device ordinal %d out of range (%d devices)", device_ordinal, n); return SZH_EINVAL; }
     SZ_HIP(hipSetDevice(device_ordinal));
-    return SZH_OK;
+    return noalloc_setup();
 }
 
 int szh_shutdown(void)

@@ -376,6 +376,112 @@ int plan_run(Plan* p, const int16_t* pcm_dev, float* feats_dev, hipStream_t stre
     return SZH_OK;
 }
 
+// ---- one clip without any allocation ------------------------------------------------------
+// szh_extract_dev_noalloc runs the same two kernels as plan_run over one clip, with the two
+// segment tables and the un-normalised MFCCs in a fixed device array instead of plan-owned
+// allocations.  The tables are filled on the device (a plan uploads them from the host).
+namespace {
+
+constexpr uint32_t kNoAllocUnit = kWinPerWave;  // base_unit() of any job this small
+constexpr uint32_t kNoAllocMaxUnits = (SZH_NOALLOC_MAX_WINDOWS + kNoAllocUnit - 1) / kNoAllocUnit;
+constexpr uint32_t kNoAllocMaxFin = (SZH_NOALLOC_MAX_WINDOWS + kSegWindows - 1) / kSegWindows;
+struct NoAllocScratch {
+    Segment units[kNoAllocMaxUnits];                  // work units of mfcc_base_kernel
+    Segment fin[kNoAllocMaxFin];                      // 48-window segments of finish_kernel
+    float base[(size_t)SZH_NOALLOC_MAX_WINDOWS * kMfcc];  // [windows][20]
+};
+// Every GPU the library runs on holds its own copy of this array (1.4 MB) until the process ends.
+// Host code never uses the name as an address: the per-device address comes from
+// hipGetSymbolAddress (noalloc_scratch) and is what the kernels receive.
+static __device__ __align__(256) unsigned char scratch[sizeof(NoAllocScratch)];
+
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mu;
+NoAllocScratch* g_scratch_ptr[kMaxDevices] = {};
+
+// the current device's copy of `scratch`; looked up once per device
+int noalloc_scratch(NoAllocScratch** out)
+{
+    int dev = 0;
+    SZ_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= kMaxDevices) { set_error("device ordinal %d is beyond the %d this call supports", dev, kMaxDevices); return SZH_EINVAL; }
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (!g_scratch_ptr[dev]) {
+        void* p = nullptr;
+        SZ_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        if (int rc = allow_dynamic_lds((const void*)mfcc_base_kernel, kBaseLdsBytes)) return rc;
+        g_scratch_ptr[dev] = static_cast<NoAllocScratch*>(p);
+    }
+    *out = g_scratch_ptr[dev];
+    return SZH_OK;
+}
+
+// the tables plan_create builds for a single file at offset 0 with n_win windows
+__global__ void single_clip_segments_kernel(Segment* __restrict__ units, uint32_t n_units, Segment* __restrict__ fin,
+                                            uint32_t n_fin, uint32_t n_win)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    for (int pass = 0; pass < 2; ++pass) {
+        const uint32_t step = pass == 0 ? kNoAllocUnit : kSegWindows;
+        if (i >= (pass == 0 ? n_units : n_fin)) continue;
+        const uint32_t w = i * step;
+        Segment s{};
+        s.pcm_off = (uint64_t)w * kHop;
+        s.win_first = w;
+        s.out_first = w;
+        s.file_win_first = 0;
+        s.n_win = n_win - w < step ? n_win - w : step;
+        s.file_n_win = n_win;
+        (pass == 0 ? units : fin)[i] = s;
+    }
+}
+
+}  // namespace
+
+int noalloc_setup()
+{
+    NoAllocScratch* p = nullptr;
+    return noalloc_scratch(&p);
+}
+
+}  // namespace sz
+
+extern "C" int szh_extract_dev_noalloc(szh_extractor* ext, const int16_t* pcm_dev, uint64_t n_samples, float* feats_dev,
+                                       void* stream)
+{
+    using namespace sz;
+    if (!ext || (n_samples && (!pcm_dev || !feats_dev))) { set_error("null argument"); return SZH_EINVAL; }
+    const uint64_t nw = szh_window_count(n_samples);
+    if (nw > (uint64_t)SZH_NOALLOC_MAX_WINDOWS) {
+        set_error("%llu windows exceed the %d-window limit of szh_extract_dev_noalloc; use szh_plan_run_dev",
+                  (unsigned long long)nw, SZH_NOALLOC_MAX_WINDOWS);
+        return SZH_EINVAL;
+    }
+    if (nw == 0) return SZH_OK;
+    if (((uintptr_t)pcm_dev & 15) != 0 || ((uintptr_t)feats_dev & 15) != 0) {
+        set_error("device buffers must be 16-byte aligned");
+        return SZH_EINVAL;
+    }
+    Extractor* e = reinterpret_cast<Extractor*>(ext);
+    NoAllocScratch* sc = nullptr;
+    if (int rc = noalloc_scratch(&sc)) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const uint32_t n_win = (uint32_t)nw;
+    const uint32_t n_units = (n_win + kNoAllocUnit - 1) / kNoAllocUnit, n_fin = (n_win + kSegWindows - 1) / kSegWindows;
+    hipLaunchKernelGGL(single_clip_segments_kernel, dim3((n_units + 255) / 256), dim3(256), 0, s, sc->units, n_units, sc->fin,
+                       n_fin, n_win);
+    SZ_HIP(hipGetLastError());
+    const uint32_t grid_a = (n_units + kBaseWaves - 1) / kBaseWaves;
+    hipLaunchKernelGGL(mfcc_base_kernel, dim3(grid_a), dim3(kBaseThreads), kBaseLdsBytes, s, pcm_dev, sc->units, n_units,
+                       e->dev, sc->base);
+    SZ_HIP(hipGetLastError());
+    hipLaunchKernelGGL(finish_kernel, dim3(n_fin), dim3(kFinishThreads), 0, s, sc->base, sc->fin, n_fin, feats_dev);
+    SZ_HIP(hipGetLastError());
+    return SZH_OK;
+}
+
+namespace sz {
+
 int augment_dev(const int16_t* in, uint64_t n, float gain, float noise_level, uint64_t shift, const float* noise_dev,
                 uint64_t seed, uint64_t counter0, int16_t* out, hipStream_t stream)
 {

@@ -68,6 +68,9 @@ int plan_create_tile(Extractor* e, uint64_t pcm_off, uint32_t lead, uint32_t n_o
 int plan_advance(Plan* p, uint64_t samples, hipStream_t stream);
 // augment (lib.rs:103-116) of n device-resident samples; noise_dev NULL -> counter-based draws
 // keyed by (seed, counter0 + i).
+// looks up the current device's copy of the fixed array szh_extract_dev_noalloc works in
+// (extract.hip); szh_init calls it so that the entry point's first call does no set-up
+int noalloc_setup();
 int augment_dev(const int16_t* in, uint64_t n, float gain, float noise_level, uint64_t shift, const float* noise_dev,
                 uint64_t seed, uint64_t counter0, int16_t* out, hipStream_t stream);
 
