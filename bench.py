@@ -105,6 +105,7 @@ def cpu_baseline(speakers, hidden, seconds):
         "value": 1.0 / per_win,
         "unit": "windows/s",
         "cores": threads,
+        "host_cpus": os.cpu_count(),
         "kind": "port",
         "sample": (f"extract: {n_clips} clips x {seconds:g} s = {n_ext} windows on {threads} OpenMP threads "
                    f"({n_ext / t_ext:.0f} windows/s); train: one epoch of {n_train} windows at batch 8, dropout 0.2, "
@@ -194,8 +195,8 @@ def main():
     ap.add_argument("--dropout", type=float, default=0.2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to "
-                    "rehearse the multi-rank path on fewer GPUs than ranks)")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal of the N > 1 path on fewer GPUs than ranks: "
+                    "ranks share a GPU and the gradient vectors are summed on the host instead of by RCCL")
     ap.add_argument("--no-extras", action="store_true", help="skip the inference and batch-8 side measurements")
     args = ap.parse_args()
 
@@ -205,19 +206,25 @@ def main():
     # BENCH_FORCE_DIST=1 takes the multi-rank path with a single rank (rehearsal of the collective on one GPU)
     multi = world > 1 or bool(os.environ.get("BENCH_FORCE_DIST"))
     if multi:
+        # torch.distributed is the control plane only (rendezvous, barriers, the max over ranks of the
+        # elapsed time): a gloo group over the loopback interface.  The data-path collective is the
+        # library's own RCCL all-reduce on the gradient vector (szh_net_allreduce_grad_dev).
         import torch.distributed as dist
-        if args.backend == "nccl":
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            local_rank %= torch.cuda.device_count()  # rehearsal: ranks may share a GPU
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group(args.backend)
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+        if args.share_gpu:
+            local_rank %= torch.cuda.device_count()  # rehearsal: ranks share a GPU, gradients summed on the host
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("gloo")
     else:
         dist = None
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local_rank if multi else 0)
-    sz.lib().szh_init(dev.index)
+    sz._capi._check(sz.lib().szh_init(dev.index))
+    comm = None
+    if multi and not args.share_gpu:
+        ident = [sz.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ident, src=0)
+        comm = sz.Comm(ident[0], rank, world)  # ncclCommInitRank: collective over the ranks
 
     # ---- synthetic, device-resident inputs
     pcm, offsets, lengths = synth_clips(args.clips, args.seconds, args.speakers, dev, first_clip=rank * args.clips)
@@ -230,10 +237,8 @@ def main():
     labels = torch.from_numpy(np.repeat(clip_speaker, per_file).astype(np.int32)).to(dev)
     net = sz.SimpleNeuralNet(60, args.hidden1, args.hidden2, args.speakers, seed=42)  # same init on every rank
     grad = torch.as_tensor(_DevView(net.grad_ptr(), net.grad_len()), device=dev)
-    # RCCL reduces a torch-owned staging copy of the 0.67 MB vector (two device copies per step)
-    # rather than library-owned memory it has never seen
-    rdev = dev if args.backend == "nccl" else torch.device("cpu")  # gloo rehearsal reduces on the host
-    gstage = torch.empty(grad.shape, dtype=grad.dtype, device=rdev) if multi else None
+    if comm is not None:
+        comm.broadcast_params(net, 0, torch.cuda.current_stream().cuda_stream)
     stream = torch.cuda.current_stream().cuda_stream
 
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
@@ -246,10 +251,12 @@ def main():
             ev[1].record()
         net.zero_grad_dev(stream)
         net.accumulate_dev(feats.data_ptr(), labels.data_ptr(), n_win, args.dropout, 1000 + k, stream)
-        if dist is not None:
-            gstage.copy_(grad)
-            dist.all_reduce(gstage)  # sums gradients, loss and live-row count over ranks
-            grad.copy_(gstage)
+        if comm is not None:
+            comm.allreduce_grad(net, stream)  # gradients, loss and live-row count summed over ranks, in place
+        elif dist is not None:  # --share-gpu rehearsal
+            host = grad.cpu()
+            dist.all_reduce(host)
+            grad.copy_(host)
         net.apply_grad_dev(args.lr, stream)
         if record:
             ev[2].record()
@@ -278,7 +285,7 @@ def main():
     loss_sum, live = [float(v) for v in grad[-2:].tolist()]
 
     if dist is not None:
-        tmax = torch.tensor([elapsed], device=rdev, dtype=torch.float64)
+        tmax = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     if rank != 0:
@@ -339,7 +346,7 @@ def main():
                          f"{args.speakers} speakers, net 60-{H1}-{H2}-{C}"),
             "windows_per_gpu": n_win,
             "batch": "one optimiser step per epoch over all windows (gradients summed on device"
-                     + (", RCCL all-reduce across ranks)" if world > 1 else ")"),
+                     + (", one in-place RCCL all-reduce of the gradient vector across ranks)" if comm is not None else ")"),
             "epochs_per_step": 1,
             "dropout": args.dropout,
             "lr": args.lr,

@@ -263,6 +263,30 @@ int szh_net_forward_dev(szh_net *net, const float *feats_dev, uint64_t n, float 
 int szh_net_vote_dev(szh_net *net, const float *feats_dev, uint64_t n, float threshold,
                      unsigned long long *counts_dev, void *stream);
 
+/* ---- the collective of a sharded epoch (RCCL over xGMI) --------------------------------- */
+/* No counterpart in the reference, which trains in one process (lib.rs:632-665, the loop the
+ * shards split).  One process per GPU: each calls szh_init(local rank), builds the same net,
+ * accumulates on its own files, and the ranks sum their gradient vectors in place before the
+ * identical apply step.  librccl.so.1 is opened by the first of these calls, not at load time.
+ *
+ * szh_comm_unique_id: rank 0 draws the 128-byte id (ncclGetUniqueId) and hands it to the other
+ * ranks by any host-side channel (pipe, file, environment).
+ * szh_comm_create: collective over the `world` ranks (blocks until all have called), on the
+ * current device.  world == 1 with id == NULL makes a communicator whose calls do nothing. */
+#define SZH_COMM_ID_BYTES 128
+typedef struct szh_comm szh_comm;
+int szh_comm_unique_id(uint8_t id[SZH_COMM_ID_BYTES]);
+int szh_comm_create(const uint8_t id[SZH_COMM_ID_BYTES], int rank, int world, szh_comm **comm);
+void szh_comm_destroy(szh_comm *comm);
+int szh_comm_rank(const szh_comm *comm);
+int szh_comm_world(const szh_comm *comm);
+/* Sum over ranks of the gradient vector (szh_net_grad_len floats at szh_net_grad_dev, the loss
+ * sum and live-row count in its tail included), in place, enqueued on `stream` behind the
+ * accumulate kernels: no staging copy.  Every rank must call it with a net of the same shape. */
+int szh_net_allreduce_grad_dev(szh_net *net, szh_comm *comm, void *stream);
+/* The parameters of rank `root` replace those of every other rank (start of a sharded run). */
+int szh_net_broadcast_params_dev(szh_net *net, szh_comm *comm, int root, void *stream);
+
 /* ---- model metadata and persistence -------------------------------------------------- */
 
 /* record_training_file, lib.rs:855-862; file_lists, lib.rs:865-867. */

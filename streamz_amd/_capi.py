@@ -85,6 +85,13 @@ _SIGS = {
     "szh_net_apply_grad_dev": (C.c_int, [C.c_void_p, C.c_float, C.c_void_p]),
     "szh_net_forward_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
     "szh_net_vote_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_float, C.c_void_p, C.c_void_p]),
+    "szh_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "szh_comm_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "szh_comm_destroy": (None, [C.c_void_p]),
+    "szh_comm_rank": (C.c_int, [C.c_void_p]),
+    "szh_comm_world": (C.c_int, [C.c_void_p]),
+    "szh_net_allreduce_grad_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "szh_net_broadcast_params_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "szh_net_record_training_file": (C.c_int, [C.c_void_p, C.c_uint32, C.c_char_p]),
     "szh_net_file_list": (C.c_int64, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64]),
     "szh_net_set_dataset_specs": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint16]),
@@ -182,6 +189,38 @@ class FeatureExtractor:
         ln = np.array([c.size for c in clips], np.uint64)
         _check(lib().szh_extract_batch(self._h, pp, _p(ln), n, po))
         return outs
+
+
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id():
+    """The id rank 0 draws and hands to the other ranks (bytes)."""
+    buf = (C.c_uint8 * COMM_ID_BYTES)()
+    _check(lib().szh_comm_unique_id(buf))
+    return bytes(buf)
+
+
+class Comm:
+    """The ranks of a sharded run (szh_comm_*): RCCL communicator on the current device."""
+
+    def __init__(self, comm_id, rank, world):
+        h = C.c_void_p()
+        buf = (C.c_uint8 * COMM_ID_BYTES).from_buffer_copy(comm_id) if comm_id is not None else None
+        _check(lib().szh_comm_create(buf, rank, world, C.byref(h)))
+        self._h = h
+        self.rank, self.world = rank, world
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().szh_comm_destroy(self._h)
+            self._h = None
+
+    def allreduce_grad(self, net, stream=0):
+        _check(lib().szh_net_allreduce_grad_dev(net._h, self._h, C.c_void_p(stream)))
+
+    def broadcast_params(self, net, root=0, stream=0):
+        _check(lib().szh_net_broadcast_params_dev(net._h, self._h, root, C.c_void_p(stream)))
 
 
 class Plan:

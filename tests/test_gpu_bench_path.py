@@ -1,0 +1,177 @@
+"""Parity of the calls the benchmark times, under their own randomness and at the wide
+configuration's own shape, plus train_from_feature_map and the seeded initialisation."""
+import os
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import pytest
+
+from helpers import dropout_keep, grad_view, mix64
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def sz():
+    import streamz_amd
+    return streamz_amd
+
+
+@pytest.fixture(scope="module")
+def po():
+    from oracle import pyoracle
+    return pyoracle
+
+
+def _oracle_grad_threads(onet, x, labels, threads=16):
+    """oracle gradient of many rows, the rows spread over host threads (ctypes releases the GIL)"""
+    parts = np.array_split(np.arange(len(x)), threads)
+    with ThreadPoolExecutor(threads) as pool:
+        gs = list(pool.map(lambda ix: onet.grad(x[ix[0]:ix[-1] + 1], labels=labels[ix[0]:ix[-1] + 1]).astype(np.float64),
+                           [p for p in parts if len(p)]))
+    return np.sum(gs, axis=0)
+
+
+@pytest.mark.parametrize("dims,n", [((60, 512, 256, 16), 5000), ((60, 512, 256, 64), 3000)])
+def test_accumulate_dev_with_seeded_dropout_matches_oracle(sz, po, dims, n):
+    """szh_net_accumulate_dev(dropout=0.2, seed) as bench.py calls it: the mask is rebuilt on the
+    host from the same counter-based generator and the masked rows go to the oracle
+    (lib.rs:119-129 no rescale, lib.rs:607-609 rows that end all-zero do not count)."""
+    import torch
+    rng = np.random.default_rng(31)
+    onet = po.Net(*dims)
+    params = [rng.uniform(-0.5, 0.5, s).astype(np.float32) for s in onet.shapes()]
+    onet.set_params(params)
+    net = sz.SimpleNeuralNet(*dims, init=params)
+    x = rng.standard_normal((n, 60)).astype(np.float32)
+    x[11, 3:] = 0.0   # three non-zero inputs: some seeds drop all of them
+    x[12] = 0.0
+    labels = rng.integers(0, dims[3], n).astype(np.int32)
+    p, seed = 0.2, 1003
+    keep = dropout_keep(seed, n, p)
+    assert 0.78 < keep.mean() < 0.82
+    xm = np.where(keep, x, np.float32(0.0))
+    live = np.any(xm != 0.0, axis=1)
+    assert not live[12]
+    dx, dl = torch.from_numpy(x).cuda(), torch.from_numpy(labels).cuda()
+    s = torch.cuda.current_stream().cuda_stream
+    net.zero_grad_dev(s)
+    net.accumulate_dev(dx.data_ptr(), dl.data_ptr(), n, p, seed, s)
+    torch.cuda.synchronize()
+    g = grad_view(net).cpu().numpy()
+    want = onet.grad(xm[live], labels=labels[live])
+    scale = np.abs(want).max()
+    np.testing.assert_allclose(g[:-2], want, atol=2e-5 * scale)
+    assert g[-1] == live.sum()
+    probs = onet.forward(xm[live])
+    loss = -np.log(np.maximum(probs[np.arange(live.sum()), labels[live]], 1e-12)).sum()
+    assert abs(g[-2] - loss) < 1e-4 * loss
+    # another seed is another mask
+    net.zero_grad_dev(s)
+    net.accumulate_dev(dx.data_ptr(), dl.data_ptr(), n, p, seed + 1, s)
+    torch.cuda.synchronize()
+    assert np.abs(grad_view(net).cpu().numpy()[:-2] - g[:-2]).max() > 1e-3 * scale
+
+
+def test_accumulate_dev_at_the_wide_configuration(sz, po):
+    """60-2048-2048-256 (the widest configuration): the chunked accumulate path with the GEMM output
+    layer and the wave-per-row softmax, on 4 096 rows, against the oracle's gradient."""
+    import torch
+    rng = np.random.default_rng(41)
+    dims = (60, 2048, 2048, 256)
+    onet = po.Net(*dims)
+    # weights scaled so that the activations stay in tanh's responsive range at this width
+    params = [(rng.uniform(-0.5, 0.5, s) * (0.08 if len(s) == 2 and s[0] > 60 else 1.0)).astype(np.float32)
+              for s in onet.shapes()]
+    onet.set_params(params)
+    net = sz.SimpleNeuralNet(*dims, init=params)
+    n = 4096
+    x = rng.standard_normal((n, 60)).astype(np.float32)
+    labels = rng.integers(0, 256, n).astype(np.int32)
+    dx, dl = torch.from_numpy(x).cuda(), torch.from_numpy(labels).cuda()
+    s = torch.cuda.current_stream().cuda_stream
+    net.zero_grad_dev(s)
+    net.accumulate_dev(dx.data_ptr(), dl.data_ptr(), n, stream=s)
+    torch.cuda.synchronize()
+    g = grad_view(net).cpu().numpy()
+    want = _oracle_grad_threads(onet, x, labels)
+    scale = np.abs(want).max()
+    np.testing.assert_allclose(g[:-2], want, atol=3e-5 * scale)
+    assert g[-1] == n
+    probs = onet.forward(x[:512])
+    np.testing.assert_allclose(net.forward(x[:512]), probs, atol=1e-4)
+
+
+def _shuffle_orders(seed, n_win, epochs):
+    """the Fisher-Yates orders pretrain_from_features draws from `seed` (one draw counter per call)"""
+    seed = np.uint64(seed)
+    draw, out = 0, []
+    for _ in range(epochs):
+        order = list(range(n_win))
+        if n_win > 1:
+            js = mix64(seed ^ mix64(np.arange(draw, draw + n_win - 1, dtype=np.uint64)))
+            draw += n_win - 1
+            for t, i in enumerate(range(n_win, 1, -1)):
+                j = int(js[t] % np.uint64(i))
+                order[i - 1], order[j] = order[j], order[i - 1]
+        out.append(order)
+    return np.array(out, np.uint32).reshape(epochs, n_win)
+
+
+@pytest.mark.parametrize("dims,batch", [((60, 64, 32, 3), 8), ((60, 48, 20, 3), 5)])
+def test_train_from_feature_map_matches_per_file_loop_and_oracle(sz, po, dims, batch):
+    """train_from_feature_map (lib.rs:632-665): files in list order, a path missing from the map is
+    skipped, the mean of the per-file losses comes back, every trained file is recorded.  Compared
+    with the library's own per-file loop (bit for bit) and with the oracle fed the same shuffles."""
+    rng = np.random.default_rng(51)
+    params = [rng.uniform(-0.5, 0.5, s).astype(np.float32) for s in po.Net(*dims).shapes()]
+    fmap = {"a.wav": rng.standard_normal((37, 60)).astype(np.float32),
+            "b.wav": rng.standard_normal((8, 60)).astype(np.float32),
+            "d.wav": rng.standard_normal((21, 60)).astype(np.float32)}
+    fmap["b.wav"][2] = 0.0
+    files = [("a.wav", 0), ("b.wav", 2), ("missing.wav", 1), ("d.wav", 1)]
+    epochs, lr, seed = 3, 0.05, 99
+    net = sz.SimpleNeuralNet(*dims, init=params)
+    loss = sz.train_from_feature_map(net, fmap, files, epochs, lr, 0.0, batch, seed=seed)
+    assert net.file_lists() == [["a.wav"], ["d.wav"], ["b.wav"]]   # record_training_file, lib.rs:655
+
+    loop = sz.SimpleNeuralNet(*dims, init=params)
+    onet = po.Net(*dims)
+    onet.set_params(params)
+    losses, olosses = [], []
+    for f, (path, cls) in enumerate(files):
+        if path not in fmap:
+            continue
+        fseed = int(mix64(np.uint64(seed + f)))
+        losses.append(sz.pretrain_from_features(loop, fmap[path], cls, dims[3], epochs, lr, 0.0, batch, seed=fseed))
+        perm = _shuffle_orders(fseed, len(fmap[path]), epochs)
+        olosses.append(onet.pretrain_from_features(fmap[path], cls, dims[3], epochs, lr, 0.0, batch, perm=perm))
+    np.testing.assert_array_equal(net.get_flat(), loop.get_flat())
+    assert loss == np.float32(np.sum(np.array(losses, np.float32), dtype=np.float32) / np.float32(len(losses)))
+    want = np.concatenate([p.ravel() for p in onet.get_params()])
+    np.testing.assert_allclose(net.get_flat(), want, atol=1e-4)
+    assert abs(loss - np.mean(olosses)) < 1e-4 * max(1.0, abs(np.mean(olosses)))
+    # nothing to train on: 0.0 (lib.rs:660-664)
+    assert sz.train_from_feature_map(net, {}, files, 1, lr, 0.0, batch) == 0.0
+
+
+def test_seeded_initialisation(sz):
+    """SimpleNeuralNet::new (lib.rs:767-790): weights uniform in [-0.5, 0.5), biases zero; here the
+    draw is a function of the seed."""
+    dims = (60, 512, 256, 16)
+    a = sz.SimpleNeuralNet(*dims, seed=42).get_params()
+    b = sz.SimpleNeuralNet(*dims, seed=42).get_params()
+    c = sz.SimpleNeuralNet(*dims, seed=43).get_params()
+    for p, q in zip(a, b):
+        np.testing.assert_array_equal(p, q)
+    for i in (1, 3, 5):
+        assert not a[i].any()
+    for i in (0, 2, 4):
+        w = a[i]
+        assert w.min() >= -0.5 and w.max() < 0.5
+        assert abs(w.mean()) < 4 * np.sqrt(1 / 12 / w.size)
+        assert abs(w.var() - 1 / 12) < 0.01
+        assert np.unique(w).size > 0.99 * min(w.size, 1 << 22) * 0.5
+        assert not np.array_equal(w, c[i])
+    # layers do not repeat each other's stream
+    assert not np.array_equal(a[0].ravel()[:1000], a[2].ravel()[:1000])
