@@ -171,6 +171,37 @@ int pretrain_epochs_dev(Net* n, const float* d_win, uint64_t n_win, const float*
     };
     int rc;
     const uint64_t steps_per_epoch = (n_win + bs - 1) / bs;
+    DevBuf d_perm, d_keep;
+    // one epoch as launches per layer and step: the path of batch sizes above 8, and of a group of
+    // epochs whose resident kernel did not run
+    auto epoch_per_layer = [&](uint32_t ep, const uint32_t* host_order) -> int {
+        if (!d_perm.p) { rc = d_perm.alloc(n_win * sizeof(uint32_t)); if (rc) return rc; }
+        if (have_keep && !d_keep.p) { rc = d_keep.alloc(n_win * kFeat); if (rc) return rc; }
+        SZ_HIP(hipMemcpyAsync(d_perm.p, host_order, n_win * sizeof(uint32_t), hipMemcpyHostToDevice, nullptr));
+        if (have_keep)
+            SZ_HIP(hipMemcpyAsync(d_keep.p, rng->keep + (size_t)ep * n_win * kFeat, n_win * kFeat, hipMemcpyHostToDevice,
+                                  nullptr));
+        SZ_HIP(hipStreamSynchronize(nullptr));  // the caller reuses host_order
+        for (uint64_t c0 = 0; c0 < n_win; c0 += bs) {
+            AccumArgs a;
+            a.x_dev = d_win;
+            a.rows = std::min<uint64_t>(bs, n_win - c0);
+            a.perm_dev = d_perm.as<uint32_t>() + c0;
+            a.keep_dev = have_keep ? d_keep.as<uint8_t>() + c0 * kFeat : nullptr;
+            a.dropout = dropout;
+            a.seed = seed;
+            a.row_counter0 = (uint64_t)ep * n_win + c0;
+            a.target_dev = d_tgt;
+            a.skip_zero_rows = true;
+            rc = net_zero_grad(n, nullptr);
+            if (rc) return rc;
+            rc = net_accumulate(n, a, nullptr);
+            if (rc) return rc;
+            rc = net_apply(n, lr, nullptr);
+            if (rc) return rc;
+        }
+        return net_zero_grad(n, nullptr);  // folds the last step's loss into the running totals
+    };
     // Batches of up to 8 rows (the reference's CLI uses 8) run as one resident kernel per group of
     // epochs: all their shuffles (and injected masks) are uploaded first.
     const uint64_t group = std::max<uint64_t>(1, std::min<uint64_t>(n_epochs, (16ull << 20) / n_win));
@@ -195,42 +226,23 @@ int pretrain_epochs_dev(Net* n, const float* d_win, uint64_t n_win, const float*
             rc = net_pretrain_steps(n, d_win, (uint32_t)n_win, d_perms.as<uint32_t>(),
                                     have_keep ? d_keeps.as<uint8_t>() : nullptr, dropout, mix64(seed + ep_first + e0), d_tgt,
                                     ne, (uint32_t)bs, lr, nullptr);
+            if (rc == SZH_STEP_NOT_RUN) {  // parameters untouched: the same epochs, same shuffles, layer by layer
+                for (uint32_t e = 0; e < ne; ++e) {
+                    rc = epoch_per_layer(ep_first + e0 + e, orders.data() + (size_t)e * n_win);
+                    if (rc) return rc;
+                }
+            }
             if (rc) return rc;
         }
         return SZH_OK;
     }
-    DevBuf d_perm, d_keep;
-    rc = d_perm.alloc(n_win * sizeof(uint32_t));
-    if (rc) return rc;
-    if (have_keep) { rc = d_keep.alloc(n_win * kFeat); if (rc) return rc; }
     for (uint32_t ep = ep_first; ep < ep_first + n_epochs; ++ep) {
         rc = shuffle_epoch(ep);
         if (rc) return rc;
-        SZ_HIP(hipMemcpyAsync(d_perm.p, order.data(), n_win * sizeof(uint32_t), hipMemcpyHostToDevice, nullptr));
-        if (have_keep)
-            SZ_HIP(hipMemcpyAsync(d_keep.p, rng->keep + (size_t)ep * n_win * kFeat, n_win * kFeat, hipMemcpyHostToDevice,
-                                  nullptr));
-        SZ_HIP(hipStreamSynchronize(nullptr));  // `order` is reused by the next epoch
-        for (uint64_t c0 = 0; c0 < n_win; c0 += bs) {
-            AccumArgs a;
-            a.x_dev = d_win;
-            a.rows = std::min<uint64_t>(bs, n_win - c0);
-            a.perm_dev = d_perm.as<uint32_t>() + c0;
-            a.keep_dev = have_keep ? d_keep.as<uint8_t>() + c0 * kFeat : nullptr;
-            a.dropout = dropout;
-            a.seed = seed;
-            a.row_counter0 = (uint64_t)ep * n_win + c0;
-            a.target_dev = d_tgt;
-            a.skip_zero_rows = true;
-            rc = net_zero_grad(n, nullptr);
-            if (rc) return rc;
-            rc = net_accumulate(n, a, nullptr);
-            if (rc) return rc;
-            rc = net_apply(n, lr, nullptr);
-            if (rc) return rc;
-        }
+        rc = epoch_per_layer(ep, order.data());
+        if (rc) return rc;
     }
-    return net_zero_grad(n, nullptr);  // folds the last step's loss into the running totals
+    return SZH_OK;
 }
 
 // one-hot target of width num_classes (lib.rs:592-595), seen through the net's output width

@@ -145,6 +145,10 @@ int net_reset_totals(Net* n, hipStream_t s);
 // The reference's batch-of-8 schedule as one resident kernel (step.hip).  `applies` says whether
 // the network and batch size fit it; d_perm / d_keep hold every epoch's shuffle / dropout mask.
 bool step_kernel_applies(const Net* n, uint32_t batch_size, uint64_t n_steps);
+// net_pretrain_steps returns this (not an error) when the resident kernel could not run to the end
+// -- its workgroups would not all be resident, or one of them gave up waiting for the others --
+// and the parameters are exactly as before the call: the caller takes the per-layer path.
+constexpr int SZH_STEP_NOT_RUN = 1;
 int net_pretrain_steps(Net* n, const float* d_win, uint32_t n_win, const uint32_t* d_perm, const uint8_t* d_keep,
                        float dropout, uint64_t seed, const float* d_target, uint32_t epochs, uint32_t batch_size,
                        float lr, hipStream_t s);

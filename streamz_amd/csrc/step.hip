@@ -3,24 +3,35 @@
 //
 // A step on 8 rows is ~7 MFLOP: far too little for a launch per layer, and the steps are
 // strictly sequential.  So a small grid of workgroups stays resident for the whole call and
-// splits the first hidden layer: workgroup b owns hidden-1 units [b*HS, (b+1)*HS), i.e. the
+// splits the first hidden layer: workgroup b owns hidden-1 units [32 b, 32 b + 32), i.e. the
 // columns of w1, the entries of b1 and the ROWS of w2 that belong to them, and keeps them in LDS
 // from the first step to the last.  Per step:
 //   1. every workgroup prepares the same <= 8 input rows (gather by permutation, dropout)
 //   2. h1[:, own] = relu(x . w1[:, own] + b1[own])                       (own data only)
-//   3. partial h2 = h1[:, own] . w2[own, :]  -> global slot of this workgroup
-//   4. ONE grid-wide barrier
+//   3. partial h2 = h1[:, own] . w2[own, :]  -> this workgroup's slot in global memory
+//   4. ONE exchange: every workgroup reads every slot
 //   5. every workgroup sums the partials in the same order -> h2, then runs the output layer
 //      redundantly (w3, b3, b2 are replicated and receive bit-identical updates everywhere):
 //      softmax, loss, delta3, delta2                                      (lib.rs:1022-1034)
 //   6. delta1[:, own] = delta2 . w2[own, :]^T, then the updates of everything the workgroup
 //      owns or replicates, with the pre-update weights throughout        (lib.rs:1029-1059)
-// The partial slots are double-buffered, so one barrier per step is enough.
+// The exchange costs no cache-wide fence: the slots are written through to memory (sc1 stores),
+// every storing wave drains its stores, one lane raises the workgroup's flag (sc1), the readers
+// poll the flags and read the slots with sc1 loads only, which bypass their CU's L1.  Slots are
+// double-buffered, so one exchange per step is enough.  Every product runs on the 16x16x4 f32
+// matrix instruction with the 8 rows padded to a 16-row tile (padding rows are kept zero in LDS,
+// so no load is conditional).
+//
+// The kernel writes the trained parameters to a shadow vector; the host adopts it only if no
+// workgroup gave up waiting (bounded by wall-clock time), so a call either trains completely or
+// leaves the parameters untouched and the caller takes the per-layer path.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
 
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 
 #include "internal.h"
 #include "prof.h"
@@ -32,60 +43,43 @@ namespace sz {
 namespace {
 
 constexpr int kStepThreads = 256;
-constexpr int kStepRows = 8;   // most rows of one optimiser step
-constexpr int kStepHS = 32;    // hidden-1 units per workgroup
+constexpr int kStepRows = 8;    // most rows of one optimiser step
+constexpr int kStepHS = 32;     // hidden-1 units per workgroup
 constexpr int kStepMaxC = 32;
+constexpr int kStepIn = 60;     // inputs (pretrain_from_features works on 60 features)
 constexpr int kStepLdW1 = kStepHS + 16;  // row stride of w1 in LDS: rows k and k+1 sit 16 banks apart
+constexpr int kStepLdH1 = 16;   // h1 is kept unit-major, 16 rows per unit (rows 8..15 zero)
+constexpr int kStepMaxBlocks = 64;
+constexpr unsigned long long kStepTimeoutTicks = 200000000ull;  // 2 s of the 100 MHz wall clock
 
 struct StepArgs {
-    float* params;           // [w1|b1|w2|b2|w3|b3]
-    int in, h1, h2, out;
-    const float* win;        // [n_win][in]
+    const float* params;     // [w1|b1|w2|b2|w3|b3]
+    float* params_out;       // shadow vector, written at the end of a healthy run
+    int h1, h2, out;
+    const float* win;        // [n_win][60]
     uint32_t n_win;
     const uint32_t* perm;    // [epochs][n_win]
-    const uint8_t* keep;     // [epochs][n_win][in] explicit dropout masks, or null
+    const uint8_t* keep;     // [epochs][n_win][60] explicit dropout masks, or null
     float dropout;
     uint64_t seed;
     const float* target;     // [out]
     uint32_t epochs, bs;
     float lr;
-    float* part;             // [2][workgroups][8][h2]
-    unsigned* counter;       // grid barrier: one arrival count per workgroup, zero at launch
-    int* abort_flag;         // set when a barrier gives up (never in a healthy run)
-    double* totals;          // += {loss, live rows}
+    float* part;             // [2][workgroups][h2][8] partial second-layer sums
+    unsigned* flags;         // one arrival count per workgroup, zero at launch
+    int* abort_flag;         // set when a workgroup gives up waiting (never in a healthy run)
+    int force_abort;         // test hook: the last workgroup reports a time-out before its first step
+    double* totals;          // {loss, live rows} of this call (zero at launch)
+    unsigned long long* prof;  // profiled build only: per-phase 100 MHz ticks of workgroup 0
 };
 
-// All workgroups arrive (barrier_arrive), then all leave (barrier_wait).  Workgroup b publishes the number of barriers it has
-// reached in flags[b] (a plain release store: no read-modify-write that would queue up behind the
-// other workgroups' at one address); one lane per workgroup then waits for that workgroup's flag.
-__device__ void barrier_arrive(unsigned* flags, unsigned arrived)
-{
-    __threadfence();   // this thread's global writes are visible device-wide
-    __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store(&flags[blockIdx.x], arrived, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ bool barrier_wait(unsigned* flags, int n_blocks, unsigned arrived, int* abort_flag)
-{
-    __shared__ int ok;
-    if (threadIdx.x == 0) ok = 1;
-    __syncthreads();
-    if ((int)threadIdx.x < n_blocks) {
-        unsigned spins = 0;
-        while (__hip_atomic_load(&flags[threadIdx.x], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < arrived) {
-            __builtin_amdgcn_s_sleep(1);
-            if (++spins > (1u << 24) || __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                ok = 0;
-                break;
-            }
-        }
-    }
-    __syncthreads();
-    __threadfence();   // later reads see what the other workgroups wrote before arriving
-    return ok != 0;
-}
-
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#define SZ_MFMA16(a_, b_, c_) __builtin_amdgcn_mfma_f32_16x16x4f32((a_), (b_), (c_), 0, 0, 0)
+// The compiler sinks every LDS read to just above its use, which makes each matrix instruction
+// wait a full LDS round trip.  Phases are therefore written as "all reads; SZ_SCHED_FENCE; all
+// matrix instructions; SZ_SCHED_FENCE; epilogue", and the fence keeps the groups apart.
+#define SZ_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 
 // value of the same register in another lane of the row of 16 (DPP), for the softmax reductions
 template <int CTRL>
@@ -105,225 +99,310 @@ __device__ __forceinline__ float step_tanh(float x)
 // 16-byte boundary)
 struct StepLds {
     int w1, b1, w2, b2, w3, b3, tgt, xs, h1, d1, h2, d2, d3, red, total;
-    int ld2, ld3, ldd3, cw, k4;
-    __host__ __device__ StepLds(int in, int h2n, int c)
+    int ld2, ld3, ldd3, cw;
+    __host__ __device__ StepLds(int h2n, int cwn)
     {
-        cw = (c + 15) / 16 * 16;   // class columns, padded to whole 16-wide MFMA tiles
-        ld2 = h2n + 1;             // odd strides: rows read by different lanes hit different banks
+        cw = cwn;                  // class columns, padded to whole 16-wide MFMA tiles
+        ld2 = h2n + 4;             // = 4 mod 64: rows 4 g + j of a fragment and unit-major reads hit distinct banks
         ld3 = cw + 1;
         ldd3 = cw + 4;             // delta3 rows are read as float4
-        k4 = (in + 3) & ~3;        // K of the first layer, padded to whole MFMA steps (rows >= in are zero)
         int at = 0;
         auto take = [&](int n) { const int p = at; at += (n + 3) & ~3; return p; };
-        w1 = take(k4 * kStepLdW1); b1 = take(kStepHS); w2 = take(kStepHS * ld2); b2 = take(h2n);
-        w3 = take(h2n * ld3); b3 = take(cw); tgt = take(cw); xs = take(kStepRows * in);
-        h1 = take(kStepHS * kStepRows); d1 = take(kStepRows * kStepHS);
-        h2 = take(16 * ld2); d2 = take(16 * ld2); d3 = take(kStepRows * ldd3);
-        red = take(4 * kStepRows * std::max(std::max(h2n, kStepHS), cw));
+        w1 = take(kStepIn * kStepLdW1); b1 = take(kStepHS); w2 = take(kStepHS * ld2); b2 = take(h2n);
+        w3 = take(h2n * ld3); b3 = take(cw); tgt = take(cw); xs = take(16 * kStepIn + 16);
+        h1 = take(kStepHS * kStepLdH1); d1 = take(kStepRows * kStepHS);
+        h2 = take(16 * ld2); d2 = take(16 * ld2); d3 = take(16 * ldd3);
+        red = take(4 * kStepRows * (kStepHS > cw ? kStepHS : cw));
         total = at;
     }
 };
 
+constexpr int kStepProfSlots = 16;
+
+// H2T / CWT: hidden2 and the padded class count as compile-time constants (the shapes the
+// reference's command line uses), or 0 for "read them from the arguments".
+template <int H2T, int CWT, bool PROF>
 __global__ __launch_bounds__(kStepThreads) void step_kernel(StepArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, m16 = lane & 15, g4 = lane >> 4;
+    // PROF: wall-clock ticks spent up to each mark, summed over the steps (uniform, scalar registers)
+    unsigned long long pacc[kStepProfSlots] = {};
+    unsigned long long pt0 = 0;
+#define STEP_MARK(i) do { if (PROF) { __syncthreads(); const unsigned long long t__ = wall_clock64(); pacc[i] += t__ - pt0; pt0 = t__; } } while (0)
+    const int tid = threadIdx.x, lane = tid & 63, m16 = lane & 15, g4 = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    __builtin_assume(wave >= 0 && wave < kStepThreads / 64);
     const int NB = gridDim.x, blk = blockIdx.x;
-    const int IN = a.in, H2 = a.h2, C = a.out, HS = kStepHS;
-    const StepLds L(IN, H2, C);
-    const int LD2 = L.ld2, LD3 = L.ld3, LDD3 = L.ldd3, CW = L.cw, K4 = L.k4;
-    constexpr int LDW1 = kStepLdW1;
+    constexpr int IN = kStepIn, HS = kStepHS, LDW1 = kStepLdW1, LDH1 = kStepLdH1;
+    const int H2 = H2T ? H2T : a.h2;
+    const int C = a.out;
+    const int CW = CWT ? CWT : (C + 15) / 16 * 16;
+    const int NT = H2 / 16;  // 16-column tiles of the second layer
+    const StepLds L(H2, CW);
+    const int LD2 = L.ld2, LD3 = L.ld3, LDD3 = L.ldd3;
     const int i0 = blk * HS;
-    float* __restrict__ W1s = sm + L.w1;   // [K4][LDW1], rows >= IN zero
+    float* __restrict__ W1s = sm + L.w1;   // [60][LDW1]
     float* __restrict__ b1s = sm + L.b1;   // [HS]
     float* __restrict__ W2s = sm + L.w2;   // [HS][LD2]
     float* __restrict__ b2s = sm + L.b2;   // [H2]
     float* __restrict__ W3s = sm + L.w3;   // [H2][LD3], columns >= C zero
     float* __restrict__ b3s = sm + L.b3;   // [CW]
     float* __restrict__ tgt = sm + L.tgt;  // [CW]
-    float* __restrict__ xs = sm + L.xs;    // [8][IN]
-    float* __restrict__ h1s = sm + L.h1;   // [HS][8]   (unit-major: 8 rows contiguous)
+    float* __restrict__ xs = sm + L.xs;    // [16][60], rows 8..15 stay zero (MFMA tiles are 16 rows)
+    float* __restrict__ h1s = sm + L.h1;   // [HS][16] unit-major, rows 8..15 stay zero
     float* __restrict__ d1s = sm + L.d1;   // [8][HS]
-    float* __restrict__ h2s = sm + L.h2;   // [16][LD2], rows 8..15 stay zero (MFMA tiles are 16 rows)
+    float* __restrict__ h2s = sm + L.h2;   // [16][LD2], rows 8..15 stay zero
     float* __restrict__ d2s = sm + L.d2;   // [16][LD2], rows 8..15 stay zero
-    float* __restrict__ d3s = sm + L.d3;   // [8][LDD3]
+    float* __restrict__ d3s = sm + L.d3;   // [16][LDD3], rows 8..15 stay zero
     float* __restrict__ red = sm + L.red;  // per-wave partial results of the K-split products
-    __shared__ int live_s[kStepRows];
-    __shared__ int n_live_s;
+    int* __restrict__ live_s = reinterpret_cast<int*>(sm + L.total);  // [8] row counts, [8] live rows, [9] all flags seen
 
     const float* P = a.params;
     const size_t off_b1 = (size_t)IN * a.h1, off_w2 = off_b1 + a.h1, off_b2 = off_w2 + (size_t)a.h1 * H2,
                  off_w3 = off_b2 + H2, off_b3 = off_w3 + (size_t)H2 * C;
-    for (int e = tid; e < K4 * HS; e += kStepThreads) { const int j = e / HS, i = e - j * HS; W1s[j * LDW1 + i] = j < IN ? P[(size_t)j * a.h1 + i0 + i] : 0.0f; }
+    for (int e = tid; e < IN * HS; e += kStepThreads) { const int j = e / HS, i = e - j * HS; W1s[j * LDW1 + i] = P[(size_t)j * a.h1 + i0 + i]; }
     for (int e = tid; e < HS; e += kStepThreads) b1s[e] = P[off_b1 + i0 + e];
     for (int e = tid; e < HS * H2; e += kStepThreads) { const int i = e / H2, k = e - i * H2; W2s[i * LD2 + k] = P[off_w2 + (size_t)(i0 + i) * H2 + k]; }
     for (int e = tid; e < H2; e += kStepThreads) b2s[e] = P[off_b2 + e];
     for (int e = tid; e < H2 * LD3; e += kStepThreads) { const int k = e / LD3, c = e - k * LD3; W3s[e] = c < C ? P[off_w3 + (size_t)k * C + c] : 0.0f; }
     for (int e = tid; e < CW; e += kStepThreads) { b3s[e] = e < C ? P[off_b3 + e] : 0.0f; tgt[e] = e < C ? a.target[e] : 0.0f; }
     for (int e = tid; e < 16 * LD2; e += kStepThreads) { h2s[e] = 0.0f; d2s[e] = 0.0f; }
+    for (int e = tid; e < 16 * IN + 16; e += kStepThreads) xs[e] = 0.0f;
+    for (int e = tid; e < HS * LDH1; e += kStepThreads) h1s[e] = 0.0f;
+    for (int e = tid; e < 16 * LDD3; e += kStepThreads) d3s[e] = 0.0f;
 
     const uint32_t steps_per_epoch = (a.n_win + a.bs - 1) / a.bs;
     const uint64_t n_steps = (uint64_t)a.epochs * steps_per_epoch;
     double loss_acc = 0.0, live_acc = 0.0;
 
-    // inputs of a step: element e = r * IN + j, two per thread (8 x 60 = 480 <= 512)
-    auto load_x = [&](uint64_t step, float (&xv)[2]) {
-        const uint32_t ep = (uint32_t)(step / steps_per_epoch);
-        const uint32_t c0 = (uint32_t)(step - (uint64_t)ep * steps_per_epoch) * a.bs;
-        const uint32_t rows = min(a.bs, a.n_win - c0);
+    // Inputs of a step: element e = r * 60 + j.  Waves 1..3 fetch them, three elements per thread
+    // (8 x 60 = 480 <= 576), while wave 0 polls the flags of the exchange.  The row indices (perm)
+    // are fetched two steps ahead and the values one step ahead, so that neither of the two
+    // dependent loads is waited for.
+    constexpr int kXE = 3, kXT = kStepThreads - 64;
+    int er[kXE], ej[kXE];
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int e = tid + q * kStepThreads;
-            const int r = e / IN, j = e - r * IN;
+    for (int q = 0; q < kXE; ++q) {
+        const int e = tid >= 64 ? tid - 64 + q * kXT : kStepRows * IN;  // wave 0 holds no element
+        er[q] = e / IN; ej[q] = e - er[q] * IN;
+    }
+    struct Cursor { uint32_t ep, c0; };  // position of a step in the shuffled epochs
+    auto advance = [&](Cursor& c) { c.c0 += a.bs; if (c.c0 >= a.n_win) { c.c0 = 0; c.ep += 1; } };
+    auto rows_at = [&](const Cursor& c) -> int { return c.ep < a.epochs ? (int)min(a.bs, a.n_win - c.c0) : 0; };
+    auto load_idx = [&](const Cursor& c, uint32_t (&idx)[kXE]) {
+        const int rows = rows_at(c);
+#pragma unroll
+        for (int q = 0; q < kXE; ++q) idx[q] = er[q] < rows ? a.perm[(uint64_t)c.ep * a.n_win + c.c0 + er[q]] : 0xffffffffu;
+    };
+    auto load_val = [&](const Cursor& c, const uint32_t (&idx)[kXE], float (&xv)[kXE]) {
+#pragma unroll
+        for (int q = 0; q < kXE; ++q) {
             float v = 0.0f;
-            if (r < (int)rows) {
-                const uint64_t at = (uint64_t)ep * a.n_win + c0 + r;
-                v = a.win[(size_t)a.perm[at] * IN + j];
+            if (idx[q] != 0xffffffffu) {
+                const uint64_t at = (uint64_t)c.ep * a.n_win + c.c0 + er[q];
+                v = a.win[(size_t)idx[q] * IN + ej[q]];
                 bool drop = false;
-                if (a.keep) drop = a.keep[at * IN + j] == 0;
-                else if (a.dropout > 0.0f) drop = uniform01(a.seed, at, (uint64_t)j) < a.dropout;
+                if (a.keep) drop = a.keep[at * IN + ej[q]] == 0;
+                else if (a.dropout > 0.0f) drop = uniform01(a.seed, at, (uint64_t)ej[q]) < a.dropout;
                 if (drop) v = 0.0f;
             }
             xv[q] = v;
         }
     };
-    float xv[2];
-    if (n_steps > 0) load_x(0, xv);
-    __syncthreads();
+    Cursor cur_val{0, 0}, cur_idx{0, 0};
+    uint32_t idx[kXE];
+    float xv[kXE];
+    load_idx(cur_idx, idx);
+    load_val(cur_val, idx, xv);     // values of step 0
+    advance(cur_idx); advance(cur_val);
+    load_idx(cur_idx, idx);         // indices of step 1
+    advance(cur_idx);
+
+    // the partial slots and the flags are only ever touched by sc1 (write-through / L1-bypassing) accesses
+    const unsigned slot_bytes = kStepRows * (unsigned)H2 * 4u;
+    __amdgpu_buffer_rsrc_t part_rs = __builtin_amdgcn_make_buffer_rsrc(a.part, 0, (int)(2u * (unsigned)NB * slot_bytes), 0x00020000);
 
     const int kq = H2 / 4;  // K range of one wave in the K-split products
     bool healthy = true;
+    if (a.force_abort && blk == NB - 1) {
+        if (tid == 0) __hip_atomic_store(a.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        healthy = false;
+    }
+    __syncthreads();
+    if (PROF) pt0 = wall_clock64();
     for (uint64_t step = 0; step < n_steps && healthy; ++step) {
+        STEP_MARK(0);   // loop top
         // 1. rows of this step -> LDS; a row counts when something survived the dropout (lib.rs:607-609)
         if (tid < kStepRows) live_s[tid] = 0;
         __syncthreads();
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int e = tid + q * kStepThreads;
-            if (e < kStepRows * IN) {
-                xs[e] = xv[q];
-                if (xv[q] != 0.0f) live_s[e / IN] = 1;  // benign race: every writer stores 1
+        for (int q = 0; q < kXE; ++q)
+            if (er[q] < kStepRows) {
+                xs[er[q] * IN + ej[q]] = xv[q];
+                if (xv[q] != 0.0f) live_s[er[q]] = 1;  // benign race: every writer stores 1
             }
-        }
         __syncthreads();
         if (tid == 0) {
             int n = 0;
             for (int r = 0; r < kStepRows; ++r) n += live_s[r];
-            n_live_s = n;
+            live_s[8] = n;
         }
-        // 2. own hidden-1 units on the matrix cores: rows x units, K = inputs; wave w takes units
-        // [16 w, 16 w + 16).  Result register v of lane (unit m16, g4) is row 4 g4 + v.
+        STEP_MARK(1);   // x -> LDS
+        // 2. own hidden-1 units: rows x units, K = inputs; wave w < 2 takes units [16 w, 16 w + 16).
+        // Result register v of lane (unit m16, g4) is row 4 g4 + v.
         if (wave < HS / 16) {
             const int ib = wave * 16;
-            // all fragments first (at most 16 steps: 64 inputs), then the chain of MFMAs
-            float av[16], bv[16];
+            float av[IN / 4], bv[IN / 4];
 #pragma unroll
-            for (int st = 0; st < 16; ++st) {
-                const int k = 4 * st + g4;
-                av[st] = (m16 < kStepRows && k < IN) ? xs[m16 * IN + k] : 0.0f;
-                bv[st] = k < K4 ? W1s[k * LDW1 + ib + m16] : 0.0f;
+            for (int st = 0; st < IN / 4; ++st) {
+                av[st] = xs[m16 * IN + 4 * st + g4];
+                bv[st] = W1s[(4 * st + g4) * LDW1 + ib + m16];
             }
+            const float b = b1s[ib + m16];
+            SZ_SCHED_FENCE();
             f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int st = 0; st < 16; st += 2) {
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[st], bv[st], acc, 0, 0, 0);  // zero fragments past K4
-                acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[st + 1], bv[st + 1], acc2, 0, 0, 0);
+            for (int st = 0; st + 1 < IN / 4; st += 2) {
+                acc = SZ_MFMA16(av[st], bv[st], acc);
+                acc2 = SZ_MFMA16(av[st + 1], bv[st + 1], acc2);
             }
+            acc = SZ_MFMA16(av[IN / 4 - 1], bv[IN / 4 - 1], acc);
             acc += acc2;
             if (g4 < 2) {
-                const float b = b1s[ib + m16];
                 float4 o;
                 o.x = fmaxf(acc[0] + b, 0.0f); o.y = fmaxf(acc[1] + b, 0.0f);
                 o.z = fmaxf(acc[2] + b, 0.0f); o.w = fmaxf(acc[3] + b, 0.0f);
-                *reinterpret_cast<float4*>(h1s + (ib + m16) * kStepRows + 4 * g4) = o;
+                *reinterpret_cast<float4*>(h1s + (ib + m16) * LDH1 + 4 * g4) = o;
             }
         }
         __syncthreads();
-        // 3. partial second layer: thread = column k
+        STEP_MARK(2);   // h1
+        // 3. partial second layer: wave w takes column tiles w, w + 4, ...  The contraction index of
+        // MFMA step st, lane group g4 is unit 16 (st / 4) + 4 g4 + st % 4 (conflict-free reads of W2s).
         const unsigned buf = (unsigned)(step & 1);
-        float* my_part = a.part + ((size_t)buf * NB + blk) * kStepRows * H2;
         {
-            float af[kStepHS / 4];  // h1[row m16][unit 4 st + g4], shared by every column tile
+            float af[HS / 4];
 #pragma unroll
-            for (int st = 0; st < kStepHS / 4; ++st) af[st] = m16 < kStepRows ? h1s[(4 * st + g4) * kStepRows + m16] : 0.0f;
-            const int nt = H2 / 16;  // column tiles; wave w takes tiles w, w + 4, w + 8, w + 12
-            f32x4 acc[4];
+            for (int st = 0; st < HS / 4; ++st) af[st] = h1s[(16 * (st >> 2) + 4 * g4 + (st & 3)) * LDH1 + m16];
+            float bf[4][HS / 4];
+            int tt[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int u = 0; u < 4; ++u) {
+                tt[u] = min(wave + 4 * u, NT - 1);  // a tile index past the end is clamped and its result dropped
 #pragma unroll
-            for (int st = 0; st < kStepHS / 4; ++st)
+                for (int st = 0; st < HS / 4; ++st) bf[u][st] = W2s[(16 * (st >> 2) + 4 * g4 + (st & 3)) * LD2 + 16 * tt[u] + m16];
+            }
+            SZ_SCHED_FENCE();
+            f32x4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-                for (int u = 0; u < 4; ++u)  // a tile index past the end is clamped and its result dropped
-                    acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[st], W2s[(4 * st + g4) * LD2 + 16 * min(wave + 4 * u, nt - 1) + m16], acc[u], 0, 0, 0);
-            if (g4 < 2) {
+            for (int st = 0; st < HS / 4; ++st)
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    if (wave + 4 * u < nt) {
+                for (int u = 0; u < 4; ++u) acc[u] = SZ_MFMA16(af[st], bf[u][st], acc[u]);
+            SZ_SCHED_FENCE();
+            // slot layout [column][8 rows]: lane (column m16, g4 < 2) stores rows 4 g4 .. 4 g4 + 3 as 16 bytes
 #pragma unroll
-                        for (int v = 0; v < 4; ++v) my_part[(4 * g4 + v) * H2 + 16 * (wave + 4 * u) + m16] = acc[u][v];
+            for (int u = 0; u < 4; ++u)
+                if (g4 < 2 && wave + 4 * u < NT)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[u]), part_rs,
+                                                           (buf * NB + blk) * slot_bytes + ((16 * tt[u] + m16) * kStepRows + 4 * g4) * 4u, 0, 16);
+        }
+        STEP_MARK(3);   // partial h2 computed and stored
+        // 4. publish: every storing wave drains its write-through stores, then one lane raises the flag
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            __hip_atomic_store(&a.flags[blk], (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            live_s[9] = 1;
+        }
+        STEP_MARK(4);   // drain + flag
+        if (wave == 0) {
+            // wave 0 waits for every workgroup's flag
+            if (lane < NB) {
+                const unsigned long long t0 = wall_clock64();
+                while (__hip_atomic_load(&a.flags[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(step + 1)) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (wall_clock64() - t0 > kStepTimeoutTicks || __hip_atomic_load(a.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                        __hip_atomic_store(a.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        live_s[9] = 0;
+                        break;
                     }
-            }
-        }
-        // 4. everybody's partials are out
-        barrier_arrive(a.counter, (unsigned)(step + 1));
-        // the next step's inputs (index arithmetic, dropout draws, loads) while the others arrive
-        if (step + 1 < n_steps) load_x(step + 1, xv);
-        healthy = barrier_wait(a.counter, NB, (unsigned)(step + 1), a.abort_flag);
-        if (!healthy) break;
-        // 5a. h2 = tanh(b2 + sum of the partials).  Wave w sums workgroups w, w+4, ... with 16-byte
-        // loads (4 columns per lane), all issued before the first add; the four waves' sums are
-        // then combined in a fixed order, the same in every workgroup.
-        {
-            const float* pb = a.part + (size_t)buf * NB * kStepRows * H2;
-            const int c4 = 4 * lane;
-            float4 s[kStepRows];
-#pragma unroll
-            for (int r = 0; r < kStepRows; ++r) s[r] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (c4 < H2) {
-                for (int b0 = wave; b0 < NB; b0 += 16) {
-                    float4 v[4][kStepRows];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-#pragma unroll
-                        for (int r = 0; r < kStepRows; ++r)
-                            v[q][r] = b0 + 4 * q < NB
-                                          ? *reinterpret_cast<const float4*>(pb + ((size_t)(b0 + 4 * q) * kStepRows + r) * H2 + c4)
-                                          : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-#pragma unroll
-                        for (int r = 0; r < kStepRows; ++r) {
-                            s[r].x += v[q][r].x; s[r].y += v[q][r].y; s[r].z += v[q][r].z; s[r].w += v[q][r].w;
-                        }
                 }
+            }
+        } else {
+            // the others fetch the next step's values and the indices of the one after
+            load_val(cur_val, idx, xv);
+            load_idx(cur_idx, idx);
+        }
+        advance(cur_val);
+        advance(cur_idx);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // no instruction: keeps the slot loads below the poll
+        __syncthreads();
+        healthy = live_s[9] != 0;
+        if (!healthy) break;
+        STEP_MARK(6);   // flags seen
+        // 5a. h2 = tanh(b2 + sum of the partials), workgroups in index order (the same in every
+        // workgroup).  A slot is 2 H2 pieces of 16 bytes: piece q holds rows 4 (q & 1) .. + 3 of
+        // column q >> 1; a thread takes pieces tid and tid + 256.  All loads are sc1 and issued
+        // before the first add.
+        {
+            f32x4 s[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+            const int np = 2 * H2;
+            for (int b0 = 0; b0 < NB; b0 += 16) {
+                u32x4 v[2][16];
 #pragma unroll
-                for (int r = 0; r < kStepRows; ++r)
-                    *reinterpret_cast<float4*>(red + ((size_t)wave * kStepRows + r) * H2 + c4) = s[r];
+                for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+                    for (int b = 0; b < 16; ++b)
+                        if (pp == 0 || np > kStepThreads)
+                            v[pp][b] = __builtin_amdgcn_raw_buffer_load_b128(
+                                part_rs, (buf * NB + min(b0 + b, NB - 1)) * slot_bytes + (unsigned)min(tid + pp * kStepThreads, np - 1) * 16u, 0, 16);
+#pragma unroll
+                for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+                    for (int b = 0; b < 16; ++b)
+                        if ((pp == 0 || np > kStepThreads) && b0 + b < NB) s[pp] += __builtin_bit_cast(f32x4, v[pp][b]);
+            }
+#pragma unroll
+            for (int pp = 0; pp < 2; ++pp) {
+                const int q = tid + pp * kStepThreads;
+                if (q < np) {
+                    const int col = q >> 1, r0 = 4 * (q & 1);
+                    const float bb = b2s[col];
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) h2s[(r0 + v) * LD2 + col] = step_tanh(bb + s[pp][v]);
+                }
             }
         }
         __syncthreads();
-        if (tid < H2) {
-#pragma unroll
-            for (int r = 0; r < kStepRows; ++r) {
-                const float t = (red[(0 * kStepRows + r) * H2 + tid] + red[(1 * kStepRows + r) * H2 + tid]) +
-                                (red[(2 * kStepRows + r) * H2 + tid] + red[(3 * kStepRows + r) * H2 + tid]);
-                h2s[r * LD2 + tid] = step_tanh(b2s[tid] + t);
-            }
-        }
-        __syncthreads();
-        // 5b. logits = h2 . w3 on the matrix cores, K split over the four waves
-        for (int cb = 0; cb < CW; cb += 16) {
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        STEP_MARK(7);   // partials summed, tanh
+        // 5b. logits = h2 . w3, K split over the four waves
+        {
+            constexpr int kMaxSt = 16;  // hidden2 <= 256: at most 64 columns per wave
             const int kb = wave * kq + g4;
-#pragma unroll 4
-            for (int st = 0; st < kq; st += 4)
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(h2s[m16 * LD2 + kb + st], W3s[(kb + st) * LD3 + cb + m16], acc, 0, 0, 0);
-            if (g4 < 2) {
+            float af[kMaxSt];
 #pragma unroll
-                for (int v = 0; v < 4; ++v) red[((size_t)wave * kStepRows + 4 * g4 + v) * CW + cb + m16] = acc[v];
+            for (int st = 0; st < kMaxSt; ++st) af[st] = 4 * st < kq ? h2s[m16 * LD2 + kb + 4 * st] : 0.0f;
+            for (int cb = 0; cb < CW; cb += 16) {
+                float bf[kMaxSt];
+#pragma unroll
+                for (int st = 0; st < kMaxSt; ++st) bf[st] = 4 * st < kq ? W3s[(kb + 4 * st) * LD3 + cb + m16] : 0.0f;
+                SZ_SCHED_FENCE();
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int st = 0; st < kMaxSt; st += 2) {
+                    if (4 * st < kq) acc = SZ_MFMA16(af[st], bf[st], acc);
+                    if (4 * (st + 1) < kq) acc2 = SZ_MFMA16(af[st + 1], bf[st + 1], acc2);
+                }
+                SZ_SCHED_FENCE();
+                acc += acc2;
+                if (g4 < 2) {
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) red[((size_t)wave * kStepRows + 4 * g4 + v) * CW + cb + m16] = acc[v];
+                }
             }
         }
         __syncthreads();
+        STEP_MARK(8);   // logits
         // softmax, loss with the pre-update weights, delta3 = o - t (lib.rs:611-615, 1028):
         // thread = (row, class); a row's classes sit in 16 (or 32) neighbouring lanes
         if (tid < kStepRows * CW) {
@@ -346,51 +425,67 @@ __global__ __launch_bounds__(kStepThreads) void step_kernel(StepArgs a)
             d3s[r * LDD3 + c] = (cls && alive) ? o - t : 0.0f;
         }
         __syncthreads();
-        const int n_live = n_live_s;
+        STEP_MARK(9);   // softmax, delta3
+        const int n_live = live_s[8];
         const float scale = n_live > 0 ? a.lr / (float)n_live : 0.0f;  // lib.rs:1047
-        // delta2 = (delta3 . w3^T)(1 - h2^2), lib.rs:1034, on the matrix cores: rows x columns of
-        // h2, K = classes; column tiles are dealt to the waves
+        // delta2 = (delta3 . w3^T)(1 - h2^2), lib.rs:1034: rows x columns of h2, K = classes; column
+        // tiles are dealt to the waves
         {
             float af[kStepMaxC / 4];  // delta3[row m16][class 4 st + g4]
 #pragma unroll
-            for (int st = 0; st < kStepMaxC / 4; ++st)  // zero past the classes: those steps add nothing
-                af[st] = (4 * st < CW && m16 < kStepRows) ? d3s[m16 * LDD3 + 4 * st + g4] : 0.0f;
-            const int nt = H2 / 16;
-            f32x4 acc[4];
+            for (int st = 0; st < kStepMaxC / 4; ++st) af[st] = 4 * st < CW ? d3s[m16 * LDD3 + 4 * st + g4] : 0.0f;
+            float bf[4][kStepMaxC / 4], hv[4][4];
+            int tt[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int u = 0; u < 4; ++u) {
+                tt[u] = min(wave + 4 * u, NT - 1);
+#pragma unroll
+                for (int st = 0; st < kStepMaxC / 4; ++st) bf[u][st] = 4 * st < CW ? W3s[(16 * tt[u] + m16) * LD3 + 4 * st + g4] : 0.0f;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) hv[u][v] = h2s[(4 * (g4 & 1) + v) * LD2 + 16 * tt[u] + m16];
+            }
+            SZ_SCHED_FENCE();
+            f32x4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
             for (int st = 0; st < kStepMaxC / 4; ++st)
+                if (4 * st < CW) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[st], W3s[(16 * min(wave + 4 * u, nt - 1) + m16) * LD3 + min(4 * st + g4, CW - 1)], acc[u], 0, 0, 0);
-            if (g4 < 2) {
+                    for (int u = 0; u < 4; ++u) acc[u] = SZ_MFMA16(af[st], bf[u][st], acc[u]);
+                }
+            SZ_SCHED_FENCE();
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    if (wave + 4 * u < nt) {
+            for (int u = 0; u < 4; ++u)
+                if (g4 < 2 && wave + 4 * u < NT) {
 #pragma unroll
-                        for (int v = 0; v < 4; ++v) {
-                            const int at = (4 * g4 + v) * LD2 + 16 * (wave + 4 * u) + m16;
-                            const float h = h2s[at];
-                            d2s[at] = acc[u][v] * (1.0f - h * h);
-                        }
-                    }
-            }
+                    for (int v = 0; v < 4; ++v) d2s[(4 * g4 + v) * LD2 + 16 * tt[u] + m16] = acc[u][v] * (1.0f - hv[u][v] * hv[u][v]);
+                }
         }
         __syncthreads();
+        STEP_MARK(10);  // delta2
         if (n_live > 0) {
-            // 6a. delta1 of the own units, delta2 . w2[own, :]^T with the old w2, on the matrix
-            // cores: K split over the waves, two tiles of 16 units
+            // 6a. delta1 of the own units, delta2 . w2[own, :]^T with the old w2: K split over the
+            // waves, two tiles of 16 units
             {
                 static_assert(kStepHS == 32, "two tiles of 16 units");
-                f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+                constexpr int kMaxSt = 16;
                 const int kb = wave * kq + g4;
-#pragma unroll 4
-                for (int st = 0; st < kq; st += 4) {
-                    const float dv = d2s[m16 * LD2 + kb + st];
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(dv, W2s[m16 * LD2 + kb + st], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(dv, W2s[(16 + m16) * LD2 + kb + st], acc1, 0, 0, 0);
+                float dv[kMaxSt], w0[kMaxSt], w1[kMaxSt];
+#pragma unroll
+                for (int st = 0; st < kMaxSt; ++st) {
+                    const bool on = 4 * st < kq;
+                    dv[st] = on ? d2s[m16 * LD2 + kb + 4 * st] : 0.0f;
+                    w0[st] = on ? W2s[m16 * LD2 + kb + 4 * st] : 0.0f;
+                    w1[st] = on ? W2s[(16 + m16) * LD2 + kb + 4 * st] : 0.0f;
                 }
+                SZ_SCHED_FENCE();
+                f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int st = 0; st < kMaxSt; ++st)
+                    if (4 * st < kq) {
+                        acc0 = SZ_MFMA16(dv[st], w0[st], acc0);
+                        acc1 = SZ_MFMA16(dv[st], w1[st], acc1);
+                    }
+                SZ_SCHED_FENCE();
                 if (g4 < 2) {
 #pragma unroll
                     for (int v = 0; v < 4; ++v) {
@@ -399,35 +494,41 @@ __global__ __launch_bounds__(kStepThreads) void step_kernel(StepArgs a)
                     }
                 }
             }
-            // 6b. replicated output layer: dW3 = h2^T . delta3 on the matrix cores (rows of w3 x
-            // classes, K = the 8 rows); register v of lane (class m16, g4) is row 16 t + 4 g4 + v
+            // 6b. replicated output layer: dW3 = h2^T . delta3 (rows of w3 x classes, K = the 8
+            // rows); register v of lane (class m16, g4) is row 16 t + 4 g4 + v
             for (int cb = 0; cb < CW; cb += 16) {
-                const int nt = H2 / 16;
                 float bf[kStepRows / 4];
 #pragma unroll
                 for (int st = 0; st < kStepRows / 4; ++st) bf[st] = d3s[(4 * st + g4) * LDD3 + cb + m16];
-                f32x4 acc[4];
+                float hf[4][kStepRows / 4], wv[4][4];
+                int tt[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int u = 0; u < 4; ++u) {
+                    tt[u] = min(wave + 4 * u, NT - 1);
+#pragma unroll
+                    for (int st = 0; st < kStepRows / 4; ++st) hf[u][st] = h2s[(4 * st + g4) * LD2 + 16 * tt[u] + m16];
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) wv[u][v] = W3s[(16 * tt[u] + 4 * g4 + v) * LD3 + cb + m16];
+                }
+                SZ_SCHED_FENCE();
+                f32x4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
                 for (int st = 0; st < kStepRows / 4; ++st)
 #pragma unroll
-                    for (int u = 0; u < 4; ++u)
-                        acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(h2s[(4 * st + g4) * LD2 + 16 * min(wave + 4 * u, nt - 1) + m16], bf[st], acc[u], 0, 0, 0);
-                if (cb + m16 < C) {
+                    for (int u = 0; u < 4; ++u) acc[u] = SZ_MFMA16(hf[u][st], bf[st], acc[u]);
+                SZ_SCHED_FENCE();
 #pragma unroll
-                    for (int u = 0; u < 4; ++u)
-                        if (wave + 4 * u < nt) {
+                for (int u = 0; u < 4; ++u)
+                    if (cb + m16 < C && wave + 4 * u < NT) {
 #pragma unroll
-                            for (int v = 0; v < 4; ++v) W3s[(16 * (wave + 4 * u) + 4 * g4 + v) * LD3 + cb + m16] -= scale * acc[u][v];
-                        }
-                }
+                        for (int v = 0; v < 4; ++v) W3s[(16 * tt[u] + 4 * g4 + v) * LD3 + cb + m16] = wv[u][v] - scale * acc[u][v];
+                    }
             }
-            if (tid < H2) {
+            for (int k = tid; k < H2; k += kStepThreads) {
                 float g2 = 0.0f;
 #pragma unroll
-                for (int r = 0; r < kStepRows; ++r) g2 += d2s[r * LD2 + tid];
-                b2s[tid] -= scale * g2;
+                for (int r = 0; r < kStepRows; ++r) g2 += d2s[r * LD2 + k];
+                b2s[k] -= scale * g2;
             }
             if (tid < C) {
                 float g = 0.0f;
@@ -436,53 +537,74 @@ __global__ __launch_bounds__(kStepThreads) void step_kernel(StepArgs a)
                 b3s[tid] -= scale * g;
             }
             __syncthreads();
+            STEP_MARK(11);  // delta1 partial products, dW3, b2, b3
             {   // delta1: combine the waves' parts, ReLU derivative (lib.rs:1039-1040)
                 const int r = tid / HS, i = tid - r * HS;
                 const float s = (red[(0 * kStepRows + r) * HS + i] + red[(1 * kStepRows + r) * HS + i]) +
                                 (red[(2 * kStepRows + r) * HS + i] + red[(3 * kStepRows + r) * HS + i]);
-                d1s[r * HS + i] = h1s[i * kStepRows + r] > 0.0f ? s : 0.0f;
+                d1s[r * HS + i] = h1s[i * LDH1 + r] > 0.0f ? s : 0.0f;
             }
-            // 6c. own rows of w2 -= scale * h1^T . delta2 on the matrix cores (units x columns, K = the
-            // 8 rows); register v of lane (column m16, g4) is unit 16 ib + 4 g4 + v
+            // 6c. own rows of w2 -= scale * h1^T . delta2 (units x columns, K = the 8 rows);
+            // register v of lane (column m16, g4) is unit 16 ib + 4 g4 + v
             {
                 float af[2][kStepRows / 4];  // h1[row 4 st + g4][unit 16 ib + m16]
 #pragma unroll
                 for (int ib = 0; ib < 2; ++ib)
 #pragma unroll
-                    for (int st = 0; st < kStepRows / 4; ++st) af[ib][st] = h1s[(16 * ib + m16) * kStepRows + 4 * st + g4];
-                for (int t = wave; t < H2 / 16; t += 4) {
-                    const float b0 = d2s[g4 * LD2 + 16 * t + m16], b1 = d2s[(4 + g4) * LD2 + 16 * t + m16];
+                    for (int st = 0; st < kStepRows / 4; ++st) af[ib][st] = h1s[(16 * ib + m16) * LDH1 + 4 * st + g4];
+                float b0[4], b1[4], wv[4][2][4];
+                int tt[4];
 #pragma unroll
-                    for (int ib = 0; ib < 2; ++ib) {
-                        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[ib][0], b0, acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[ib][1], b1, acc, 0, 0, 0);
+                for (int u = 0; u < 4; ++u) {
+                    tt[u] = min(wave + 4 * u, NT - 1);
+                    b0[u] = d2s[g4 * LD2 + 16 * tt[u] + m16];
+                    b1[u] = d2s[(4 + g4) * LD2 + 16 * tt[u] + m16];
 #pragma unroll
-                        for (int v = 0; v < 4; ++v) W2s[(16 * ib + 4 * g4 + v) * LD2 + 16 * t + m16] -= scale * acc[v];
-                    }
+                    for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) wv[u][ib][v] = W2s[(16 * ib + 4 * g4 + v) * LD2 + 16 * tt[u] + m16];
                 }
+                SZ_SCHED_FENCE();
+                f32x4 acc[4][2];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int ib = 0; ib < 2; ++ib) acc[u][ib] = SZ_MFMA16(af[ib][0], b0[u], (f32x4{0.f, 0.f, 0.f, 0.f}));
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int ib = 0; ib < 2; ++ib) acc[u][ib] = SZ_MFMA16(af[ib][1], b1[u], acc[u][ib]);
+                SZ_SCHED_FENCE();
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (wave + 4 * u < NT) {
+#pragma unroll
+                        for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+                            for (int v = 0; v < 4; ++v) W2s[(16 * ib + 4 * g4 + v) * LD2 + 16 * tt[u] + m16] = wv[u][ib][v] - scale * acc[u][ib][v];
+                    }
             }
             __syncthreads();
-            // own columns of w1 -= scale * x^T . delta1 (inputs x units, K = the 8 rows), own b1
+            STEP_MARK(12);  // delta1 combine, w2 update
+            // own columns of w1 -= scale * x^T . delta1 (inputs x units, K = the 8 rows), own b1;
+            // wave w takes inputs [16 w, 16 w + 16) (inputs past 59 read the next row's start: finite, dropped)
             {
                 float bf[2][kStepRows / 4];  // delta1[row 4 st + g4][unit 16 ib + m16]
 #pragma unroll
                 for (int ib = 0; ib < 2; ++ib)
 #pragma unroll
                     for (int st = 0; st < kStepRows / 4; ++st) bf[ib][st] = d1s[(4 * st + g4) * HS + 16 * ib + m16];
-                for (int tj = wave; tj < (IN + 15) / 16; tj += 4) {
-                    const int j = 16 * tj + m16;
-                    const float a0 = j < IN ? xs[g4 * IN + j] : 0.0f, a1 = j < IN ? xs[(4 + g4) * IN + j] : 0.0f;
+                const int j = 16 * wave + m16;
+                const float a0 = xs[g4 * IN + j], a1 = xs[(4 + g4) * IN + j];
 #pragma unroll
-                    for (int ib = 0; ib < 2; ++ib) {
-                        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bf[ib][0], acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bf[ib][1], acc, 0, 0, 0);
+                for (int ib = 0; ib < 2; ++ib) {
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                    acc = SZ_MFMA16(a0, bf[ib][0], acc);
+                    acc = SZ_MFMA16(a1, bf[ib][1], acc);
 #pragma unroll
-                        for (int v = 0; v < 4; ++v) {
-                            const int jj = 16 * tj + 4 * g4 + v;
-                            if (jj < IN) W1s[jj * LDW1 + 16 * ib + m16] -= scale * acc[v];
-                        }
+                    for (int v = 0; v < 4; ++v) {
+                        const int jj = 16 * wave + 4 * g4 + v;
+                        if (jj < IN) W1s[jj * LDW1 + 16 * ib + m16] -= scale * acc[v];
                     }
                 }
             }
@@ -493,11 +615,16 @@ __global__ __launch_bounds__(kStepThreads) void step_kernel(StepArgs a)
                 b1s[tid] -= scale * g;
             }
         }
+        STEP_MARK(13);  // w1, b1 updates
         __syncthreads();
     }
 
-    // write the owned parameters back; workgroup 0 also writes the replicated ones and the totals
-    float* Pw = a.params;
+    if (PROF && blk == 0 && tid == 0)
+        for (int i = 0; i < kStepProfSlots; ++i) a.prof[i] = pacc[i];
+#undef STEP_MARK
+    if (!healthy) return;  // the host discards the shadow vector
+    // the owned parameters go to the shadow vector; workgroup 0 also writes the replicated ones and the totals
+    float* Pw = a.params_out;
     for (int e = tid; e < IN * HS; e += kStepThreads) { const int j = e / HS, i = e - j * HS; Pw[(size_t)j * a.h1 + i0 + i] = W1s[j * LDW1 + i]; }
     for (int e = tid; e < HS; e += kStepThreads) Pw[off_b1 + i0 + e] = b1s[e];
     for (int e = tid; e < HS * H2; e += kStepThreads) { const int i = e / H2, k = e - i * H2; Pw[off_w2 + (size_t)(i0 + i) * H2 + k] = W2s[i * LD2 + k]; }
@@ -510,50 +637,105 @@ __global__ __launch_bounds__(kStepThreads) void step_kernel(StepArgs a)
     }
 }
 
-size_t step_lds_bytes(int in, int h2, int c) { return (size_t)StepLds(in, h2, c).total * sizeof(float); }
+int padded_classes(uint32_t out) { return ((int)out + 15) / 16 * 16; }
+// the float arrays, then 16 ints of per-step state
+size_t step_lds_bytes(int h2, int cw) { return (size_t)StepLds(h2, cw).total * sizeof(float) + 64; }
+
+typedef void (*StepFn)(StepArgs);
+template <bool PROF>
+StepFn pick_step_kernel(int h2, int cw)
+{
+    if (h2 == 256 && cw == 16) return step_kernel<256, 16, PROF>;
+    if (h2 == 256 && cw == 32) return step_kernel<256, 32, PROF>;
+    if (h2 == 128 && cw == 16) return step_kernel<128, 16, PROF>;
+    return step_kernel<0, 0, PROF>;
+}
 
 }  // namespace
 
 bool step_kernel_applies(const Net* n, uint32_t batch_size, uint64_t n_steps)
 {
-    return n_steps * (n->h1 / kStepHS + 1) < 0x7fffffffull && batch_size >= 1 && batch_size <= (uint32_t)kStepRows && n->in >= 1 && n->in <= 64 &&
-           kStepRows * n->in <= 2 * kStepThreads && n->h1 % kStepHS == 0 && n->h1 / kStepHS >= 1 && n->h1 / kStepHS <= 64 &&
-           n->h2 >= 16 && n->h2 % 16 == 0 && n->h2 <= (uint32_t)kStepThreads && n->out >= 1 && n->out <= (uint32_t)kStepMaxC &&
-           kStepHS * kStepRows == kStepThreads;
+    return n_steps < 0x7fffffffull && batch_size >= 1 && batch_size <= (uint32_t)kStepRows && n->in == (uint32_t)kStepIn &&
+           n->h1 % kStepHS == 0 && n->h1 / kStepHS >= 1 && n->h1 / kStepHS <= (uint32_t)kStepMaxBlocks && n->h2 >= 16 &&
+           n->h2 % 16 == 0 && n->h2 <= 256 && n->out >= 1 && n->out <= (uint32_t)kStepMaxC && kStepHS * kStepRows == kStepThreads;
 }
 
 int net_pretrain_steps(Net* n, const float* d_win, uint32_t n_win, const uint32_t* d_perm, const uint8_t* d_keep,
                        float dropout, uint64_t seed, const float* d_target, uint32_t epochs, uint32_t batch_size,
                        float lr, hipStream_t s)
 {
+    // STREAMZ_STEP_FORCE_ABORT (test hook): 1 = a workgroup reports a time-out, the caller falls back;
+    // 2 = the same, reported as an error instead
+    static const int env_mode = [] { const char* v = std::getenv("STREAMZ_STEP_FORCE_ABORT"); return v ? std::atoi(v) : 0; }();
+    // STREAMZ_STEP_PROF=1: the instrumented instantiation, per-phase times of workgroup 0 to stderr
+    static const bool prof_on = [] { const char* v = std::getenv("STREAMZ_STEP_PROF"); return v && v[0] == '1'; }();
     const int nb = (int)(n->h1 / kStepHS);
-    struct Scratch { float* part = nullptr; unsigned* counter = nullptr; int* abort_flag = nullptr; };
-    Scratch sc;
-    const size_t part_bytes = 2ull * nb * kStepRows * n->h2 * sizeof(float);
-    SZ_HIP(hipMalloc((void**)&sc.part, part_bytes + 64 + 64 * sizeof(unsigned)));
-    sc.counter = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(sc.part) + part_bytes);
-    sc.abort_flag = reinterpret_cast<int*>(sc.counter + 64);   // after the (at most 64) workgroup flags
-    hipError_t e = hipMemsetAsync(sc.counter, 0, 64 + 64 * sizeof(unsigned), s);
+    const int cw = padded_classes(n->out);
+    const size_t lds = step_lds_bytes((int)n->h2, cw);
+    StepFn fn = prof_on ? pick_step_kernel<true>((int)n->h2, cw) : pick_step_kernel<false>((int)n->h2, cw);
+    SZ_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    // every workgroup must be resident at once: the exchange waits for all of them
+    int per_cu = 0, dev = 0, cus = 0;
+    SZ_HIP(hipGetDevice(&dev));
+    SZ_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    SZ_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)fn, kStepThreads, lds));
+    if ((long)per_cu * cus < nb) return SZH_STEP_NOT_RUN;
+
+    // one allocation: [partial slots | shadow parameters | flags + abort word (zeroed)]
+    const size_t part_bytes = (2ull * nb * kStepRows * n->h2 * sizeof(float) + 255) / 256 * 256;
+    const size_t shadow_bytes = (n->param_count() * sizeof(float) + 255) / 256 * 256;
+    const size_t flag_bytes = 512;  // 64 flags, the abort word, at byte 384 the call's {loss, live rows}
+    char* base = nullptr;
+    SZ_HIP(hipMalloc((void**)&base, part_bytes + shadow_bytes + flag_bytes));
+    struct Free { char* p; ~Free() { (void)hipFree(p); } } guard{base};
     StepArgs a{};
     a.params = n->d_params;
-    a.in = (int)n->in; a.h1 = (int)n->h1; a.h2 = (int)n->h2; a.out = (int)n->out;
+    a.params_out = reinterpret_cast<float*>(base + part_bytes);
+    a.h1 = (int)n->h1; a.h2 = (int)n->h2; a.out = (int)n->out;
     a.win = d_win; a.n_win = n_win; a.perm = d_perm; a.keep = d_keep; a.dropout = dropout; a.seed = seed;
     a.target = d_target; a.epochs = epochs; a.bs = batch_size; a.lr = lr;
-    a.part = sc.part; a.counter = sc.counter; a.abort_flag = sc.abort_flag;
-    a.totals = n->d_stats + 2;
-    const size_t lds = step_lds_bytes(a.in, a.h2, a.out);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    int abort_host = 0;
-    if (e == hipSuccess) {
+    a.part = reinterpret_cast<float*>(base);
+    a.flags = reinterpret_cast<unsigned*>(base + part_bytes + shadow_bytes);
+    a.abort_flag = reinterpret_cast<int*>(a.flags + kStepMaxBlocks);
+    a.force_abort = env_mode != 0 ? 1 : 0;
+    a.totals = reinterpret_cast<double*>(reinterpret_cast<char*>(a.flags) + 384);
+    SZ_HIP(hipMemsetAsync(a.flags, 0, flag_bytes, s));
+    unsigned long long* d_prof = nullptr;
+    if (prof_on) { SZ_HIP(hipMalloc((void**)&d_prof, kStepProfSlots * sizeof(unsigned long long))); a.prof = d_prof; }
+    struct FreeProf { unsigned long long* p; ~FreeProf() { if (p) (void)hipFree(p); } } guard2{d_prof};
+    {
         ProfScope prof("steps", s);
-        hipLaunchKernelGGL(step_kernel, dim3(nb), dim3(kStepThreads), lds, s, a);
-        e = hipGetLastError();
+        hipLaunchKernelGGL(fn, dim3(nb), dim3(kStepThreads), lds, s, a);
     }
-    if (e == hipSuccess) e = hipMemcpyAsync(&abort_host, sc.abort_flag, sizeof(int), hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
-    (void)hipFree(sc.part);
-    if (e != hipSuccess) return hip_fail(e, "step kernel");
-    if (abort_host) { set_error("training step kernel: grid barrier timed out"); return SZH_ENODEVICE; }
+    SZ_HIP(hipGetLastError());
+    struct { int abort; int pad[31]; double totals[2]; } tail;  // bytes 256 .. 400 of the flag block
+    static_assert(sizeof(tail) == 144, "abort word at 256, totals at 384");
+    SZ_HIP(hipMemcpyAsync(&tail, a.abort_flag, sizeof(tail), hipMemcpyDeviceToHost, s));
+    SZ_HIP(hipStreamSynchronize(s));
+    const int abort_host = tail.abort;
+    if (d_prof) {
+        unsigned long long h[kStepProfSlots] = {};
+        if (hipMemcpy(h, d_prof, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
+            const uint64_t n_steps = (uint64_t)epochs * ((n_win + batch_size - 1) / batch_size);
+            std::fprintf(stderr, "step_kernel phases, ns per step over %llu steps:", (unsigned long long)n_steps);
+            for (int i = 0; i < kStepProfSlots; ++i) std::fprintf(stderr, " [%d] %.0f", i, 10.0 * (double)h[i] / (double)(n_steps ? n_steps : 1));
+            std::fprintf(stderr, "\n");
+        }
+    }
+    if (abort_host) {
+        // some workgroup gave up waiting: nothing was adopted, the parameters are as before the call
+        if (env_mode == 2) { set_error("training step kernel: a workgroup timed out waiting for the others; parameters unchanged"); return SZH_ENODEVICE; }
+        return SZH_STEP_NOT_RUN;
+    }
+    // adopt the shadow parameters and add the call's loss / live-row sums to the running totals
+    SZ_HIP(hipMemcpyAsync(n->d_params, a.params_out, n->param_count() * sizeof(float), hipMemcpyDeviceToDevice, s));
+    double run[2];
+    SZ_HIP(hipMemcpyAsync(run, n->d_stats + 2, sizeof(run), hipMemcpyDeviceToHost, s));
+    SZ_HIP(hipStreamSynchronize(s));
+    run[0] += tail.totals[0];
+    run[1] += tail.totals[1];
+    SZ_HIP(hipMemcpyAsync(n->d_stats + 2, run, sizeof(run), hipMemcpyHostToDevice, s));
+    SZ_HIP(hipStreamSynchronize(s));
     return SZH_OK;
 }
 
