@@ -49,6 +49,7 @@ constexpr int kStepMaxC = 32;
 constexpr int kStepIn = 60;     // inputs (pretrain_from_features works on 60 features)
 constexpr int kStepLdW1 = kStepHS + 16;  // row stride of w1 in LDS: rows k and k+1 sit 16 banks apart
 constexpr int kStepLdH1 = 16;   // h1 is kept unit-major, 16 rows per unit (rows 8..15 zero)
+constexpr int kStepXs = 16 * kStepIn + 16;  // one buffer of input rows [16][60] + pad (floats)
 constexpr int kStepMaxBlocks = 64;
 constexpr unsigned long long kStepTimeoutTicks = 200000000ull;  // 2 s of the 100 MHz wall clock
 
@@ -98,21 +99,21 @@ __device__ __forceinline__ float step_tanh(float x)
 // LDS layout, shared by the kernel and the host-side size computation (floats, every piece on a
 // 16-byte boundary)
 struct StepLds {
-    int w1, b1, w2, b2, w3, b3, tgt, xs, h1, d1, h2, d2, d3, red, total;
+    int w1, b1, w2, b2, w3, b3, tgt, xs, h1, d1, h2, d2, d3, red, red2, total;
     int ld2, ld3, ldd3, cw;
     __host__ __device__ StepLds(int h2n, int cwn)
     {
         cw = cwn;                  // class columns, padded to whole 16-wide MFMA tiles
         ld2 = h2n + 4;             // = 4 mod 64: rows 4 g + j of a fragment and unit-major reads hit distinct banks
         ld3 = cw + 1;
-        ldd3 = cw + 4;             // delta3 rows are read as float4
+        ldd3 = cw + 4;
         int at = 0;
         auto take = [&](int n) { const int p = at; at += (n + 3) & ~3; return p; };
         w1 = take(kStepIn * kStepLdW1); b1 = take(kStepHS); w2 = take(kStepHS * ld2); b2 = take(h2n);
-        w3 = take(h2n * ld3); b3 = take(cw); tgt = take(cw); xs = take(16 * kStepIn + 16);
+        w3 = take(h2n * ld3); b3 = take(cw); tgt = take(cw); xs = take(2 * kStepXs);
         h1 = take(kStepHS * kStepLdH1); d1 = take(kStepRows * kStepHS);
-        h2 = take(16 * ld2); d2 = take(16 * ld2); d3 = take(16 * ldd3);
-        red = take(4 * kStepRows * (kStepHS > cw ? kStepHS : cw));
+        h2 = take(16 * ld2); d2 = take(16 * ld2); d3 = take(4 * 16 * ldd3);
+        red = take(4 * kStepRows * cw); red2 = take(4 * kStepRows * kStepHS);
         total = at;
     }
 };
@@ -121,6 +122,12 @@ constexpr int kStepProfSlots = 16;
 
 // H2T / CWT: hidden2 and the padded class count as compile-time constants (the shapes the
 // reference's command line uses), or 0 for "read them from the arguments".
+//
+// Wave w owns the 16-column tiles [w TPW, (w + 1) TPW) of the second layer (TPW = tiles / 4, rounded
+// up) in every phase that is indexed by those columns: the sums of the exchange, its share of the
+// K-split products (logits, delta1), delta2, dW3 (the same rows of w3), b2 and dW2.  What one
+// phase writes there, only the same wave reads in the next, so those phases follow each other
+// without a workgroup barrier (a wavefront's LDS operations execute in program order).
 template <int H2T, int CWT, bool PROF>
 __global__ __launch_bounds__(kStepThreads) void step_kernel(StepArgs a)
 {
@@ -133,11 +140,14 @@ __global__ __launch_bounds__(kStepThreads) void step_kernel(StepArgs a)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     __builtin_assume(wave >= 0 && wave < kStepThreads / 64);
     const int NB = gridDim.x, blk = blockIdx.x;
-    constexpr int IN = kStepIn, HS = kStepHS, LDW1 = kStepLdW1, LDH1 = kStepLdH1;
+    constexpr int IN = kStepIn, HS = kStepHS, LDW1 = kStepLdW1, LDH1 = kStepLdH1, TPWMAX = 4;
     const int H2 = H2T ? H2T : a.h2;
     const int C = a.out;
     const int CW = CWT ? CWT : (C + 15) / 16 * 16;
-    const int NT = H2 / 16;  // 16-column tiles of the second layer
+    const int NT = H2 / 16;              // 16-column tiles of the second layer
+    const int TPW = (NT + 3) / 4;        // tiles per wave
+    const int t0 = wave * TPW;           // this wave's first tile
+    const int ntw = max(0, min(TPW, NT - t0));  // and how many it owns
     const StepLds L(H2, CW);
     const int LD2 = L.ld2, LD3 = L.ld3, LDD3 = L.ldd3;
     const int i0 = blk * HS;
@@ -148,14 +158,15 @@ __global__ __launch_bounds__(kStepThreads) void step_kernel(StepArgs a)
     float* __restrict__ W3s = sm + L.w3;   // [H2][LD3], columns >= C zero
     float* __restrict__ b3s = sm + L.b3;   // [CW]
     float* __restrict__ tgt = sm + L.tgt;  // [CW]
-    float* __restrict__ xs = sm + L.xs;    // [16][60], rows 8..15 stay zero (MFMA tiles are 16 rows)
+    float* __restrict__ xsb = sm + L.xs;   // 2 x [16][60] (+ pad): this step's rows / the next step's; rows 8..15 stay zero
     float* __restrict__ h1s = sm + L.h1;   // [HS][16] unit-major, rows 8..15 stay zero
     float* __restrict__ d1s = sm + L.d1;   // [8][HS]
     float* __restrict__ h2s = sm + L.h2;   // [16][LD2], rows 8..15 stay zero
     float* __restrict__ d2s = sm + L.d2;   // [16][LD2], rows 8..15 stay zero
-    float* __restrict__ d3s = sm + L.d3;   // [16][LDD3], rows 8..15 stay zero
-    float* __restrict__ red = sm + L.red;  // per-wave partial results of the K-split products
-    int* __restrict__ live_s = reinterpret_cast<int*>(sm + L.total);  // [8] row counts, [8] live rows, [9] all flags seen
+    float* __restrict__ d3w = sm + L.d3 + wave * 16 * LDD3;  // this wave's copy of delta3 [16][LDD3], rows 8..15 zero
+    float* __restrict__ red = sm + L.red;  // [4 waves][8][CW] K-split parts of the logits
+    float* __restrict__ red2 = sm + L.red2;  // [4 waves][8][HS] K-split parts of delta1
+    int* __restrict__ ctl = reinterpret_cast<int*>(sm + L.total);  // [2][8] live rows of this / the next step, [16] all flags seen
 
     const float* P = a.params;
     const size_t off_b1 = (size_t)IN * a.h1, off_w2 = off_b1 + a.h1, off_b2 = off_w2 + (size_t)a.h1 * H2,
@@ -167,23 +178,24 @@ __global__ __launch_bounds__(kStepThreads) void step_kernel(StepArgs a)
     for (int e = tid; e < H2 * LD3; e += kStepThreads) { const int k = e / LD3, c = e - k * LD3; W3s[e] = c < C ? P[off_w3 + (size_t)k * C + c] : 0.0f; }
     for (int e = tid; e < CW; e += kStepThreads) { b3s[e] = e < C ? P[off_b3 + e] : 0.0f; tgt[e] = e < C ? a.target[e] : 0.0f; }
     for (int e = tid; e < 16 * LD2; e += kStepThreads) { h2s[e] = 0.0f; d2s[e] = 0.0f; }
-    for (int e = tid; e < 16 * IN + 16; e += kStepThreads) xs[e] = 0.0f;
+    for (int e = tid; e < 2 * kStepXs; e += kStepThreads) xsb[e] = 0.0f;
     for (int e = tid; e < HS * LDH1; e += kStepThreads) h1s[e] = 0.0f;
-    for (int e = tid; e < 16 * LDD3; e += kStepThreads) d3s[e] = 0.0f;
+    for (int e = tid; e < 4 * 16 * LDD3; e += kStepThreads) (sm + L.d3)[e] = 0.0f;
+    if (tid < 17) ctl[tid] = 0;
 
     const uint32_t steps_per_epoch = (a.n_win + a.bs - 1) / a.bs;
     const uint64_t n_steps = (uint64_t)a.epochs * steps_per_epoch;
     double loss_acc = 0.0, live_acc = 0.0;
 
-    // Inputs of a step: element e = r * 60 + j.  Waves 1..3 fetch them, three elements per thread
-    // (8 x 60 = 480 <= 576), while wave 0 polls the flags of the exchange.  The row indices (perm)
-    // are fetched two steps ahead and the values one step ahead, so that neither of the two
-    // dependent loads is waited for.
-    constexpr int kXE = 3, kXT = kStepThreads - 64;
+    // Inputs of a step: element e = r * 60 + j, two per thread (8 x 60 = 480 <= 512).  The row
+    // indices (perm) are fetched two steps ahead and the values one step ahead, so that neither of
+    // the two dependent loads is waited for; the address arithmetic and the dropout draws sit
+    // behind the issue of the exchange's loads, whose latency covers them.
+    constexpr int kXE = 2;
     int er[kXE], ej[kXE];
 #pragma unroll
     for (int q = 0; q < kXE; ++q) {
-        const int e = tid >= 64 ? tid - 64 + q * kXT : kStepRows * IN;  // wave 0 holds no element
+        const int e = tid + q * kStepThreads;
         er[q] = e / IN; ej[q] = e - er[q] * IN;
     }
     struct Cursor { uint32_t ep, c0; };  // position of a step in the shuffled epochs
@@ -209,6 +221,15 @@ __global__ __launch_bounds__(kStepThreads) void step_kernel(StepArgs a)
             xv[q] = v;
         }
     };
+    // rows of a step -> LDS buffer `b`; a row counts when something survived the dropout (lib.rs:607-609)
+    auto stage_rows = [&](int b, const float (&xv)[kXE]) {
+#pragma unroll
+        for (int q = 0; q < kXE; ++q)
+            if (er[q] < kStepRows) {
+                xsb[b * kStepXs + er[q] * IN + ej[q]] = xv[q];
+                if (xv[q] != 0.0f) ctl[8 * b + er[q]] = 1;  // benign race: every writer stores 1
+            }
+    };
     Cursor cur_val{0, 0}, cur_idx{0, 0};
     uint32_t idx[kXE];
     float xv[kXE];
@@ -217,12 +238,13 @@ __global__ __launch_bounds__(kStepThreads) void step_kernel(StepArgs a)
     advance(cur_idx); advance(cur_val);
     load_idx(cur_idx, idx);         // indices of step 1
     advance(cur_idx);
+    __syncthreads();
+    stage_rows(0, xv);
 
     // the partial slots and the flags are only ever touched by sc1 (write-through / L1-bypassing) accesses
     const unsigned slot_bytes = kStepRows * (unsigned)H2 * 4u;
     __amdgpu_buffer_rsrc_t part_rs = __builtin_amdgcn_make_buffer_rsrc(a.part, 0, (int)(2u * (unsigned)NB * slot_bytes), 0x00020000);
 
-    const int kq = H2 / 4;  // K range of one wave in the K-split products
     bool healthy = true;
     if (a.force_abort && blk == NB - 1) {
         if (tid == 0) __hip_atomic_store(a.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -231,24 +253,15 @@ __global__ __launch_bounds__(kStepThreads) void step_kernel(StepArgs a)
     __syncthreads();
     if (PROF) pt0 = wall_clock64();
     for (uint64_t step = 0; step < n_steps && healthy; ++step) {
-        STEP_MARK(0);   // loop top
-        // 1. rows of this step -> LDS; a row counts when something survived the dropout (lib.rs:607-609)
-        if (tid < kStepRows) live_s[tid] = 0;
-        __syncthreads();
+        const int cb_ = (int)(step & 1);                 // LDS buffer of this step's rows / live flags
+        const float* __restrict__ xs = xsb + cb_ * kStepXs;
+        const unsigned buf = (unsigned)(step & 1);       // exchange slot of this step
+        // tiles of this wave, clamped for the loads; tile u counts when u < ntw
+        int tt[TPWMAX];
 #pragma unroll
-        for (int q = 0; q < kXE; ++q)
-            if (er[q] < kStepRows) {
-                xs[er[q] * IN + ej[q]] = xv[q];
-                if (xv[q] != 0.0f) live_s[er[q]] = 1;  // benign race: every writer stores 1
-            }
-        __syncthreads();
-        if (tid == 0) {
-            int n = 0;
-            for (int r = 0; r < kStepRows; ++r) n += live_s[r];
-            live_s[8] = n;
-        }
-        STEP_MARK(1);   // x -> LDS
-        // 2. own hidden-1 units: rows x units, K = inputs; wave w < 2 takes units [16 w, 16 w + 16).
+        for (int u = 0; u < TPWMAX; ++u) tt[u] = min(t0 + min(u, TPW - 1), NT - 1);
+        STEP_MARK(0);
+        // 1. own hidden-1 units: rows x units, K = inputs; wave w < 2 takes units [16 w, 16 w + 16).
         // Result register v of lane (unit m16, g4) is row 4 g4 + v.
         if (wave < HS / 16) {
             const int ib = wave * 16;
@@ -276,123 +289,121 @@ __global__ __launch_bounds__(kStepThreads) void step_kernel(StepArgs a)
             }
         }
         __syncthreads();
-        STEP_MARK(2);   // h1
-        // 3. partial second layer: wave w takes column tiles w, w + 4, ...  The contraction index of
-        // MFMA step st, lane group g4 is unit 16 (st / 4) + 4 g4 + st % 4 (conflict-free reads of W2s).
-        const unsigned buf = (unsigned)(step & 1);
+        STEP_MARK(1);   // h1
+        // 2. partial second layer, own column tiles.  The contraction index of MFMA step st, lane
+        // group g4 is unit 16 (st / 4) + 4 g4 + st % 4 (conflict-free reads of W2s).
         {
-            float af[HS / 4];
+            float af[HS / 4], bf[TPWMAX][HS / 4];
 #pragma unroll
             for (int st = 0; st < HS / 4; ++st) af[st] = h1s[(16 * (st >> 2) + 4 * g4 + (st & 3)) * LDH1 + m16];
-            float bf[4][HS / 4];
-            int tt[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                tt[u] = min(wave + 4 * u, NT - 1);  // a tile index past the end is clamped and its result dropped
+            for (int u = 0; u < TPWMAX; ++u)
 #pragma unroll
                 for (int st = 0; st < HS / 4; ++st) bf[u][st] = W2s[(16 * (st >> 2) + 4 * g4 + (st & 3)) * LD2 + 16 * tt[u] + m16];
-            }
             SZ_SCHED_FENCE();
-            f32x4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+            f32x4 acc[TPWMAX] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
             for (int st = 0; st < HS / 4; ++st)
 #pragma unroll
-                for (int u = 0; u < 4; ++u) acc[u] = SZ_MFMA16(af[st], bf[u][st], acc[u]);
+                for (int u = 0; u < TPWMAX; ++u) acc[u] = SZ_MFMA16(af[st], bf[u][st], acc[u]);
             SZ_SCHED_FENCE();
             // slot layout [column][8 rows]: lane (column m16, g4 < 2) stores rows 4 g4 .. 4 g4 + 3 as 16 bytes
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (g4 < 2 && wave + 4 * u < NT)
+            for (int u = 0; u < TPWMAX; ++u)
+                if (g4 < 2 && u < ntw)
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[u]), part_rs,
                                                            (buf * NB + blk) * slot_bytes + ((16 * tt[u] + m16) * kStepRows + 4 * g4) * 4u, 0, 16);
         }
-        STEP_MARK(3);   // partial h2 computed and stored
-        // 4. publish: every storing wave drains its write-through stores, then one lane raises the flag
+        STEP_MARK(2);   // partial h2 computed and stored
+        // 3. publish: every storing wave drains its write-through stores, then one lane raises the flag
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) {
             __hip_atomic_store(&a.flags[blk], (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            live_s[9] = 1;
+            ctl[16] = 1;
         }
-        STEP_MARK(4);   // drain + flag
-        if (wave == 0) {
-            // wave 0 waits for every workgroup's flag
-            if (lane < NB) {
-                const unsigned long long t0 = wall_clock64();
-                while (__hip_atomic_load(&a.flags[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(step + 1)) {
-                    __builtin_amdgcn_s_sleep(1);
-                    if (wall_clock64() - t0 > kStepTimeoutTicks || __hip_atomic_load(a.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                        __hip_atomic_store(a.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        live_s[9] = 0;
-                        break;
-                    }
+        STEP_MARK(3);   // drain + flag
+        if (wave == 0 && lane < NB) {   // wave 0 waits for every workgroup's flag
+            const unsigned long long tw0 = wall_clock64();
+            while (__hip_atomic_load(&a.flags[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(step + 1)) {
+                __builtin_amdgcn_s_sleep(1);
+                if (wall_clock64() - tw0 > kStepTimeoutTicks || __hip_atomic_load(a.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                    __hip_atomic_store(a.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ctl[16] = 0;
+                    break;
                 }
             }
-        } else {
-            // the others fetch the next step's values and the indices of the one after
-            load_val(cur_val, idx, xv);
-            load_idx(cur_idx, idx);
         }
-        advance(cur_val);
-        advance(cur_idx);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // no instruction: keeps the slot loads below the poll
         __syncthreads();
-        healthy = live_s[9] != 0;
+        healthy = ctl[16] != 0;
         if (!healthy) break;
-        STEP_MARK(6);   // flags seen
-        // 5a. h2 = tanh(b2 + sum of the partials), workgroups in index order (the same in every
-        // workgroup).  A slot is 2 H2 pieces of 16 bytes: piece q holds rows 4 (q & 1) .. + 3 of
-        // column q >> 1; a thread takes pieces tid and tid + 256.  All loads are sc1 and issued
-        // before the first add.
+        STEP_MARK(4);   // flags seen
+        // 4. h2 = tanh(b2 + sum of the partials) for the own columns, workgroups in index order (the
+        // same in every workgroup).  A slot is 2 H2 pieces of 16 bytes: piece 2 c + h holds rows
+        // 4 h .. 4 h + 3 of column c; in pass p a lane takes piece (lane & 31) of tile 2 p + lane / 32.
+        // All loads are sc1 and issued before the first add.
         {
-            f32x4 s[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-            const int np = 2 * H2;
+            f32x4 s[TPWMAX / 2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+            unsigned poff[TPWMAX / 2];
+#pragma unroll
+            for (int p = 0; p < TPWMAX / 2; ++p) poff[p] = (unsigned)(32 * tt[2 * p + (lane >> 5)] + (lane & 31)) * 16u;
             for (int b0 = 0; b0 < NB; b0 += 16) {
-                u32x4 v[2][16];
+                u32x4 v[TPWMAX / 2][16];
 #pragma unroll
-                for (int pp = 0; pp < 2; ++pp)
-#pragma unroll
-                    for (int b = 0; b < 16; ++b)
-                        if (pp == 0 || np > kStepThreads)
-                            v[pp][b] = __builtin_amdgcn_raw_buffer_load_b128(
-                                part_rs, (buf * NB + min(b0 + b, NB - 1)) * slot_bytes + (unsigned)min(tid + pp * kStepThreads, np - 1) * 16u, 0, 16);
-#pragma unroll
-                for (int pp = 0; pp < 2; ++pp)
+                for (int p = 0; p < TPWMAX / 2; ++p)
 #pragma unroll
                     for (int b = 0; b < 16; ++b)
-                        if ((pp == 0 || np > kStepThreads) && b0 + b < NB) s[pp] += __builtin_bit_cast(f32x4, v[pp][b]);
+                        if (2 * p < TPW)
+                            v[p][b] = __builtin_amdgcn_raw_buffer_load_b128(part_rs, (buf * NB + min(b0 + b, NB - 1)) * slot_bytes + poff[p], 0, 16);
+                if (b0 == 0) {
+                    // while those loads are in flight: the next step's values and the indices of the one after
+                    SZ_SCHED_FENCE();
+                    load_val(cur_val, idx, xv);
+                    load_idx(cur_idx, idx);
+                    advance(cur_val);
+                    advance(cur_idx);
+                    SZ_SCHED_FENCE();
+                }
+#pragma unroll
+                for (int p = 0; p < TPWMAX / 2; ++p)
+#pragma unroll
+                    for (int b = 0; b < 16; ++b)
+                        if (2 * p < TPW && b0 + b < NB) s[p] += __builtin_bit_cast(f32x4, v[p][b]);
             }
 #pragma unroll
-            for (int pp = 0; pp < 2; ++pp) {
-                const int q = tid + pp * kStepThreads;
-                if (q < np) {
-                    const int col = q >> 1, r0 = 4 * (q & 1);
+            for (int p = 0; p < TPWMAX / 2; ++p)
+                if (2 * p + (lane >> 5) < ntw) {
+                    const int col = 16 * tt[2 * p + (lane >> 5)] + ((lane & 31) >> 1), r0 = 4 * (lane & 1);
                     const float bb = b2s[col];
 #pragma unroll
-                    for (int v = 0; v < 4; ++v) h2s[(r0 + v) * LD2 + col] = step_tanh(bb + s[pp][v]);
+                    for (int v = 0; v < 4; ++v) h2s[(r0 + v) * LD2 + col] = step_tanh(bb + s[p][v]);
                 }
-            }
         }
-        __syncthreads();
-        STEP_MARK(7);   // partials summed, tanh
-        // 5b. logits = h2 . w3, K split over the four waves
+        STEP_MARK(5);   // partials summed, tanh
+        // 5. logits = h2 . w3, K split over the waves by their own columns
         {
-            constexpr int kMaxSt = 16;  // hidden2 <= 256: at most 64 columns per wave
-            const int kb = wave * kq + g4;
-            float af[kMaxSt];
+            float af[TPWMAX][4];
 #pragma unroll
-            for (int st = 0; st < kMaxSt; ++st) af[st] = 4 * st < kq ? h2s[m16 * LD2 + kb + 4 * st] : 0.0f;
+            for (int u = 0; u < TPWMAX; ++u)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) af[u][q] = h2s[m16 * LD2 + 16 * tt[u] + 4 * q + g4];
             for (int cb = 0; cb < CW; cb += 16) {
-                float bf[kMaxSt];
+                float bf[TPWMAX][4];
 #pragma unroll
-                for (int st = 0; st < kMaxSt; ++st) bf[st] = 4 * st < kq ? W3s[(kb + 4 * st) * LD3 + cb + m16] : 0.0f;
+                for (int u = 0; u < TPWMAX; ++u)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) bf[u][q] = W3s[(16 * tt[u] + 4 * q + g4) * LD3 + cb + m16];
                 SZ_SCHED_FENCE();
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int st = 0; st < kMaxSt; st += 2) {
-                    if (4 * st < kq) acc = SZ_MFMA16(af[st], bf[st], acc);
-                    if (4 * (st + 1) < kq) acc2 = SZ_MFMA16(af[st + 1], bf[st + 1], acc2);
-                }
+                for (int u = 0; u < TPWMAX; ++u)
+                    if (u < ntw) {
+                        acc = SZ_MFMA16(af[u][0], bf[u][0], acc);
+                        acc2 = SZ_MFMA16(af[u][1], bf[u][1], acc2);
+                        acc = SZ_MFMA16(af[u][2], bf[u][2], acc);
+                        acc2 = SZ_MFMA16(af[u][3], bf[u][3], acc2);
+                    }
                 SZ_SCHED_FENCE();
                 acc += acc2;
                 if (g4 < 2) {
@@ -401,13 +412,20 @@ __global__ __launch_bounds__(kStepThreads) void step_kernel(StepArgs a)
                 }
             }
         }
+        if (wave == 0 && lane < kStepRows) ctl[8 * (cb_ ^ 1) + lane] = 0;  // live flags of the next step: cleared before they are set in 8.
         __syncthreads();
-        STEP_MARK(8);   // logits
-        // softmax, loss with the pre-update weights, delta3 = o - t (lib.rs:611-615, 1028):
-        // thread = (row, class); a row's classes sit in 16 (or 32) neighbouring lanes
-        if (tid < kStepRows * CW) {
-            const int r = tid / CW, c = tid - r * CW;
-            const bool cls = c < C, alive = live_s[r] != 0;
+        STEP_MARK(6);   // logits
+        // 6. every wave for itself: softmax, loss with the pre-update weights, delta3 = o - t
+        // (lib.rs:611-615, 1028) -> its own copy of delta3.  Lane = (row, class); a row's classes sit
+        // in 16 (or 32) neighbouring lanes.
+        int n_live = 0;
+#pragma unroll
+        for (int r = 0; r < kStepRows; ++r) n_live += ctl[8 * cb_ + r];
+        const float scale = n_live > 0 ? a.lr / (float)n_live : 0.0f;  // lib.rs:1047
+        for (int e0 = 0; e0 < kStepRows * CW; e0 += 64) {
+            const int e = e0 + lane;
+            const int r = e / CW, c = e - r * CW;
+            const bool cls = c < C, alive = ctl[8 * cb_ + r] != 0;
             const float z = cls ? b3s[c] + ((red[(0 * kStepRows + r) * CW + c] + red[(1 * kStepRows + r) * CW + c]) +
                                             (red[(2 * kStepRows + r) * CW + c] + red[(3 * kStepRows + r) * CW + c]))
                                 : -INFINITY;
@@ -415,148 +433,137 @@ __global__ __launch_bounds__(kStepThreads) void step_kernel(StepArgs a)
             mx = fmaxf(mx, dpp16<0xB1>(mx)); mx = fmaxf(mx, dpp16<0x4E>(mx));
             mx = fmaxf(mx, dpp16<0x141>(mx)); mx = fmaxf(mx, dpp16<0x140>(mx));
             if (CW > 16) mx = fmaxf(mx, __shfl_xor(mx, 16));
-            const float e = cls ? expf(z - mx) : 0.0f;
-            float sum = e;
+            const float ex = cls ? expf(z - mx) : 0.0f;
+            float sum = ex;
             sum += dpp16<0xB1>(sum); sum += dpp16<0x4E>(sum); sum += dpp16<0x141>(sum); sum += dpp16<0x140>(sum);
             if (CW > 16) sum += __shfl_xor(sum, 16);
-            const float o = e / sum, t = tgt[c];
-            if (cls && alive && t != 0.0f) loss_acc -= (double)(t * logf(fmaxf(o, 1e-12f)));
-            if (c == 0 && alive) live_acc += 1.0;
-            d3s[r * LDD3 + c] = (cls && alive) ? o - t : 0.0f;
+            const float o = ex / sum, t = tgt[c];
+            if (wave == 0) {
+                if (cls && alive && t != 0.0f) loss_acc -= (double)(t * logf(fmaxf(o, 1e-12f)));
+                if (c == 0 && alive) live_acc += 1.0;
+            }
+            d3w[r * LDD3 + c] = (cls && alive) ? o - t : 0.0f;
         }
-        __syncthreads();
-        STEP_MARK(9);   // softmax, delta3
-        const int n_live = live_s[8];
-        const float scale = n_live > 0 ? a.lr / (float)n_live : 0.0f;  // lib.rs:1047
-        // delta2 = (delta3 . w3^T)(1 - h2^2), lib.rs:1034: rows x columns of h2, K = classes; column
-        // tiles are dealt to the waves
+        STEP_MARK(7);   // softmax, delta3
+        // 7. still every wave for itself, on its own columns.  delta2 = (delta3 . w3^T)(1 - h2^2),
+        // lib.rs:1034: rows x columns of h2, K = classes.
         {
             float af[kStepMaxC / 4];  // delta3[row m16][class 4 st + g4]
+            float bf[TPWMAX][kStepMaxC / 4], hv[TPWMAX][4];
 #pragma unroll
-            for (int st = 0; st < kStepMaxC / 4; ++st) af[st] = 4 * st < CW ? d3s[m16 * LDD3 + 4 * st + g4] : 0.0f;
-            float bf[4][kStepMaxC / 4], hv[4][4];
-            int tt[4];
+            for (int st = 0; st < kStepMaxC / 4; ++st) af[st] = 4 * st < CW ? d3w[m16 * LDD3 + 4 * st + g4] : 0.0f;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                tt[u] = min(wave + 4 * u, NT - 1);
+            for (int u = 0; u < TPWMAX; ++u) {
 #pragma unroll
                 for (int st = 0; st < kStepMaxC / 4; ++st) bf[u][st] = 4 * st < CW ? W3s[(16 * tt[u] + m16) * LD3 + 4 * st + g4] : 0.0f;
 #pragma unroll
                 for (int v = 0; v < 4; ++v) hv[u][v] = h2s[(4 * (g4 & 1) + v) * LD2 + 16 * tt[u] + m16];
             }
             SZ_SCHED_FENCE();
-            f32x4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+            f32x4 acc[TPWMAX] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
             for (int st = 0; st < kStepMaxC / 4; ++st)
                 if (4 * st < CW) {
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) acc[u] = SZ_MFMA16(af[st], bf[u][st], acc[u]);
+                    for (int u = 0; u < TPWMAX; ++u) acc[u] = SZ_MFMA16(af[st], bf[u][st], acc[u]);
                 }
             SZ_SCHED_FENCE();
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (g4 < 2 && wave + 4 * u < NT) {
+            for (int u = 0; u < TPWMAX; ++u)
+                if (g4 < 2 && u < ntw) {
 #pragma unroll
                     for (int v = 0; v < 4; ++v) d2s[(4 * g4 + v) * LD2 + 16 * tt[u] + m16] = acc[u][v] * (1.0f - hv[u][v] * hv[u][v]);
                 }
         }
-        __syncthreads();
-        STEP_MARK(10);  // delta2
+        STEP_MARK(8);   // delta2
         if (n_live > 0) {
-            // 6a. delta1 of the own units, delta2 . w2[own, :]^T with the old w2: K split over the
-            // waves, two tiles of 16 units
+            // delta1 of the own units, delta2 . w2[own, :]^T with the old w2: this wave's share of K
+            // (its own columns), two tiles of 16 units
             {
                 static_assert(kStepHS == 32, "two tiles of 16 units");
-                constexpr int kMaxSt = 16;
-                const int kb = wave * kq + g4;
-                float dv[kMaxSt], w0[kMaxSt], w1[kMaxSt];
+                float dv[TPWMAX][4], w0[TPWMAX][4], w1[TPWMAX][4];
 #pragma unroll
-                for (int st = 0; st < kMaxSt; ++st) {
-                    const bool on = 4 * st < kq;
-                    dv[st] = on ? d2s[m16 * LD2 + kb + 4 * st] : 0.0f;
-                    w0[st] = on ? W2s[m16 * LD2 + kb + 4 * st] : 0.0f;
-                    w1[st] = on ? W2s[(16 + m16) * LD2 + kb + 4 * st] : 0.0f;
-                }
+                for (int u = 0; u < TPWMAX; ++u)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int k = 16 * tt[u] + 4 * q + g4;
+                        dv[u][q] = d2s[m16 * LD2 + k];
+                        w0[u][q] = W2s[m16 * LD2 + k];
+                        w1[u][q] = W2s[(16 + m16) * LD2 + k];
+                    }
                 SZ_SCHED_FENCE();
                 f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int st = 0; st < kMaxSt; ++st)
-                    if (4 * st < kq) {
-                        acc0 = SZ_MFMA16(dv[st], w0[st], acc0);
-                        acc1 = SZ_MFMA16(dv[st], w1[st], acc1);
+                for (int u = 0; u < TPWMAX; ++u)
+                    if (u < ntw) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            acc0 = SZ_MFMA16(dv[u][q], w0[u][q], acc0);
+                            acc1 = SZ_MFMA16(dv[u][q], w1[u][q], acc1);
+                        }
                     }
                 SZ_SCHED_FENCE();
                 if (g4 < 2) {
 #pragma unroll
                     for (int v = 0; v < 4; ++v) {
-                        red[((size_t)wave * kStepRows + 4 * g4 + v) * HS + m16] = acc0[v];
-                        red[((size_t)wave * kStepRows + 4 * g4 + v) * HS + 16 + m16] = acc1[v];
+                        red2[((size_t)wave * kStepRows + 4 * g4 + v) * HS + m16] = acc0[v];
+                        red2[((size_t)wave * kStepRows + 4 * g4 + v) * HS + 16 + m16] = acc1[v];
                     }
                 }
             }
-            // 6b. replicated output layer: dW3 = h2^T . delta3 (rows of w3 x classes, K = the 8
+            STEP_MARK(9);   // delta1 parts
+            // replicated output layer, own rows of w3: dW3 = h2^T . delta3 (rows of w3 x classes, K = the 8
             // rows); register v of lane (class m16, g4) is row 16 t + 4 g4 + v
             for (int cb = 0; cb < CW; cb += 16) {
-                float bf[kStepRows / 4];
+                float bf[kStepRows / 4], hf[TPWMAX][kStepRows / 4], wv[TPWMAX][4];
 #pragma unroll
-                for (int st = 0; st < kStepRows / 4; ++st) bf[st] = d3s[(4 * st + g4) * LDD3 + cb + m16];
-                float hf[4][kStepRows / 4], wv[4][4];
-                int tt[4];
+                for (int st = 0; st < kStepRows / 4; ++st) bf[st] = d3w[(4 * st + g4) * LDD3 + cb + m16];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    tt[u] = min(wave + 4 * u, NT - 1);
+                for (int u = 0; u < TPWMAX; ++u) {
 #pragma unroll
                     for (int st = 0; st < kStepRows / 4; ++st) hf[u][st] = h2s[(4 * st + g4) * LD2 + 16 * tt[u] + m16];
 #pragma unroll
                     for (int v = 0; v < 4; ++v) wv[u][v] = W3s[(16 * tt[u] + 4 * g4 + v) * LD3 + cb + m16];
                 }
                 SZ_SCHED_FENCE();
-                f32x4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+                f32x4 acc[TPWMAX] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
                 for (int st = 0; st < kStepRows / 4; ++st)
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) acc[u] = SZ_MFMA16(hf[u][st], bf[st], acc[u]);
+                    for (int u = 0; u < TPWMAX; ++u) acc[u] = SZ_MFMA16(hf[u][st], bf[st], acc[u]);
                 SZ_SCHED_FENCE();
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    if (cb + m16 < C && wave + 4 * u < NT) {
+                for (int u = 0; u < TPWMAX; ++u)
+                    if (cb + m16 < C && u < ntw) {
 #pragma unroll
                         for (int v = 0; v < 4; ++v) W3s[(16 * tt[u] + 4 * g4 + v) * LD3 + cb + m16] = wv[u][v] - scale * acc[u][v];
                     }
             }
-            for (int k = tid; k < H2; k += kStepThreads) {
+            if (lane < 16 * ntw) {   // b2 of the own columns
+                const int k = 16 * t0 + lane;
                 float g2 = 0.0f;
 #pragma unroll
                 for (int r = 0; r < kStepRows; ++r) g2 += d2s[r * LD2 + k];
                 b2s[k] -= scale * g2;
             }
-            if (tid < C) {
+            if (wave == 0 && lane < C) {
                 float g = 0.0f;
 #pragma unroll
-                for (int r = 0; r < kStepRows; ++r) g += d3s[r * LDD3 + tid];
-                b3s[tid] -= scale * g;
+                for (int r = 0; r < kStepRows; ++r) g += d3w[r * LDD3 + lane];
+                b3s[lane] -= scale * g;
             }
-            __syncthreads();
-            STEP_MARK(11);  // delta1 partial products, dW3, b2, b3
-            {   // delta1: combine the waves' parts, ReLU derivative (lib.rs:1039-1040)
-                const int r = tid / HS, i = tid - r * HS;
-                const float s = (red[(0 * kStepRows + r) * HS + i] + red[(1 * kStepRows + r) * HS + i]) +
-                                (red[(2 * kStepRows + r) * HS + i] + red[(3 * kStepRows + r) * HS + i]);
-                d1s[r * HS + i] = h1s[i * LDH1 + r] > 0.0f ? s : 0.0f;
-            }
-            // 6c. own rows of w2 -= scale * h1^T . delta2 (units x columns, K = the 8 rows);
+            STEP_MARK(10);  // dW3, b2, b3
+            // own rows of w2, own columns: -= scale * h1^T . delta2 (units x columns, K = the 8 rows);
             // register v of lane (column m16, g4) is unit 16 ib + 4 g4 + v
             {
                 float af[2][kStepRows / 4];  // h1[row 4 st + g4][unit 16 ib + m16]
+                float b0[TPWMAX], b1[TPWMAX], wv[TPWMAX][2][4];
 #pragma unroll
                 for (int ib = 0; ib < 2; ++ib)
 #pragma unroll
                     for (int st = 0; st < kStepRows / 4; ++st) af[ib][st] = h1s[(16 * ib + m16) * LDH1 + 4 * st + g4];
-                float b0[4], b1[4], wv[4][2][4];
-                int tt[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    tt[u] = min(wave + 4 * u, NT - 1);
+                for (int u = 0; u < TPWMAX; ++u) {
                     b0[u] = d2s[g4 * LD2 + 16 * tt[u] + m16];
                     b1[u] = d2s[(4 + g4) * LD2 + 16 * tt[u] + m16];
 #pragma unroll
@@ -565,19 +572,19 @@ __global__ __launch_bounds__(kStepThreads) void step_kernel(StepArgs a)
                         for (int v = 0; v < 4; ++v) wv[u][ib][v] = W2s[(16 * ib + 4 * g4 + v) * LD2 + 16 * tt[u] + m16];
                 }
                 SZ_SCHED_FENCE();
-                f32x4 acc[4][2];
+                f32x4 acc[TPWMAX][2];
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
+                for (int u = 0; u < TPWMAX; ++u)
 #pragma unroll
                     for (int ib = 0; ib < 2; ++ib) acc[u][ib] = SZ_MFMA16(af[ib][0], b0[u], (f32x4{0.f, 0.f, 0.f, 0.f}));
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
+                for (int u = 0; u < TPWMAX; ++u)
 #pragma unroll
                     for (int ib = 0; ib < 2; ++ib) acc[u][ib] = SZ_MFMA16(af[ib][1], b1[u], acc[u][ib]);
                 SZ_SCHED_FENCE();
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    if (wave + 4 * u < NT) {
+                for (int u = 0; u < TPWMAX; ++u)
+                    if (u < ntw) {
 #pragma unroll
                         for (int ib = 0; ib < 2; ++ib)
 #pragma unroll
@@ -585,11 +592,21 @@ __global__ __launch_bounds__(kStepThreads) void step_kernel(StepArgs a)
                     }
             }
             __syncthreads();
-            STEP_MARK(12);  // delta1 combine, w2 update
+            STEP_MARK(11);  // w2 update
+            // 8. delta1: every wave combines all the waves' parts (the same sums, the same writes),
+            // ReLU derivative (lib.rs:1039-1040)
+#pragma unroll
+            for (int q = 0; q < kStepRows * HS / 64; ++q) {
+                const int e = lane + 64 * q, r = e / HS, i = e - r * HS;
+                const float s = (red2[(0 * kStepRows + r) * HS + i] + red2[(1 * kStepRows + r) * HS + i]) +
+                                (red2[(2 * kStepRows + r) * HS + i] + red2[(3 * kStepRows + r) * HS + i]);
+                d1s[r * HS + i] = h1s[i * LDH1 + r] > 0.0f ? s : 0.0f;
+            }
             // own columns of w1 -= scale * x^T . delta1 (inputs x units, K = the 8 rows), own b1;
             // wave w takes inputs [16 w, 16 w + 16) (inputs past 59 read the next row's start: finite, dropped)
             {
                 float bf[2][kStepRows / 4];  // delta1[row 4 st + g4][unit 16 ib + m16]
+                float wv[2][4];
 #pragma unroll
                 for (int ib = 0; ib < 2; ++ib)
 #pragma unroll
@@ -597,25 +614,34 @@ __global__ __launch_bounds__(kStepThreads) void step_kernel(StepArgs a)
                 const int j = 16 * wave + m16;
                 const float a0 = xs[g4 * IN + j], a1 = xs[(4 + g4) * IN + j];
 #pragma unroll
-                for (int ib = 0; ib < 2; ++ib) {
-                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-                    acc = SZ_MFMA16(a0, bf[ib][0], acc);
-                    acc = SZ_MFMA16(a1, bf[ib][1], acc);
+                for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) wv[ib][v] = W1s[min(16 * wave + 4 * g4 + v, IN - 1) * LDW1 + 16 * ib + m16];
+                SZ_SCHED_FENCE();
+                f32x4 acc[2];
+#pragma unroll
+                for (int ib = 0; ib < 2; ++ib) acc[ib] = SZ_MFMA16(a0, bf[ib][0], (f32x4{0.f, 0.f, 0.f, 0.f}));
+#pragma unroll
+                for (int ib = 0; ib < 2; ++ib) acc[ib] = SZ_MFMA16(a1, bf[ib][1], acc[ib]);
+                SZ_SCHED_FENCE();
+#pragma unroll
+                for (int ib = 0; ib < 2; ++ib)
 #pragma unroll
                     for (int v = 0; v < 4; ++v) {
                         const int jj = 16 * wave + 4 * g4 + v;
-                        if (jj < IN) W1s[jj * LDW1 + 16 * ib + m16] -= scale * acc[v];
+                        if (jj < IN) W1s[jj * LDW1 + 16 * ib + m16] = wv[ib][v] - scale * acc[ib][v];
                     }
-                }
             }
-            if (tid < HS) {
+            if (wave == 0 && lane < HS) {
                 float g = 0.0f;
 #pragma unroll
-                for (int r = 0; r < kStepRows; ++r) g += d1s[r * HS + tid];
-                b1s[tid] -= scale * g;
+                for (int r = 0; r < kStepRows; ++r) g += d1s[r * HS + lane];
+                b1s[lane] -= scale * g;
             }
         }
-        STEP_MARK(13);  // w1, b1 updates
+        // the next step's rows (fetched during the exchange) -> the other LDS buffer
+        stage_rows(cb_ ^ 1, xv);
+        STEP_MARK(12);  // delta1 combine, w1, b1 updates, next rows staged
         __syncthreads();
     }
 
@@ -632,14 +658,15 @@ __global__ __launch_bounds__(kStepThreads) void step_kernel(StepArgs a)
         for (int e = tid; e < H2; e += kStepThreads) Pw[off_b2 + e] = b2s[e];
         for (int e = tid; e < H2 * C; e += kStepThreads) { const int k = e / C, c = e - k * C; Pw[off_w3 + e] = W3s[k * LD3 + c]; }
         for (int e = tid; e < C; e += kStepThreads) Pw[off_b3 + e] = b3s[e];
+        // per-lane sums of wave 0 -> one add per lane that saw a loss term
         if (loss_acc != 0.0) atomicAdd(&a.totals[0], loss_acc);
         if (live_acc != 0.0) atomicAdd(&a.totals[1], live_acc);
     }
 }
 
 int padded_classes(uint32_t out) { return ((int)out + 15) / 16 * 16; }
-// the float arrays, then 16 ints of per-step state
-size_t step_lds_bytes(int h2, int cw) { return (size_t)StepLds(h2, cw).total * sizeof(float) + 64; }
+// the float arrays, then 17 ints of per-step state
+size_t step_lds_bytes(int h2, int cw) { return (size_t)StepLds(h2, cw).total * sizeof(float) + 128; }
 
 typedef void (*StepFn)(StepArgs);
 template <bool PROF>
