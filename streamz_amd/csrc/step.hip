@@ -48,7 +48,7 @@ constexpr int kStepHS = 32;     // hidden-1 units per workgroup
 constexpr int kStepMaxC = 32;
 constexpr int kStepIn = 60;     // inputs (pretrain_from_features works on 60 features)
 constexpr int kStepLdW1 = kStepHS + 16;  // row stride of w1 in LDS: rows k and k+1 sit 16 banks apart
-constexpr int kStepLdH1 = 16;   // h1 is kept unit-major, 16 rows per unit (rows 8..15 zero)
+constexpr int kStepLdH1 = kStepHS + 4;  // h1 is kept row-major [16 rows][units] (rows 8..15 zero); 36 = 4 mod 32
 constexpr int kStepXs = 16 * kStepIn + 16;  // one buffer of input rows [16][60] + pad (floats)
 constexpr int kStepMaxBlocks = 64;
 constexpr unsigned long long kStepTimeoutTicks = 200000000ull;  // 2 s of the 100 MHz wall clock
@@ -105,13 +105,13 @@ struct StepLds {
     {
         cw = cwn;                  // class columns, padded to whole 16-wide MFMA tiles
         ld2 = h2n + 4;             // = 4 mod 64: rows 4 g + j of a fragment and unit-major reads hit distinct banks
-        ld3 = cw + 1;
+        ld3 = h2n + 4;             // w3 is kept transposed, [class][hidden2]
         ldd3 = cw + 4;
         int at = 0;
         auto take = [&](int n) { const int p = at; at += (n + 3) & ~3; return p; };
         w1 = take(kStepIn * kStepLdW1); b1 = take(kStepHS); w2 = take(kStepHS * ld2); b2 = take(h2n);
-        w3 = take(h2n * ld3); b3 = take(cw); tgt = take(cw); xs = take(2 * kStepXs);
-        h1 = take(kStepHS * kStepLdH1); d1 = take(kStepRows * kStepHS);
+        w3 = take(cw * ld3); b3 = take(cw); tgt = take(cw); xs = take(2 * kStepXs);
+        h1 = take(16 * kStepLdH1); d1 = take(kStepRows * kStepHS);
         h2 = take(16 * ld2); d2 = take(16 * ld2); d3 = take(4 * 16 * ldd3);
         red = take(4 * kStepRows * cw); red2 = take(4 * kStepRows * kStepHS);
         total = at;
@@ -155,11 +155,11 @@ __global__ __launch_bounds__(kStepThreads) void step_kernel(StepArgs a)
     float* __restrict__ b1s = sm + L.b1;   // [HS]
     float* __restrict__ W2s = sm + L.w2;   // [HS][LD2]
     float* __restrict__ b2s = sm + L.b2;   // [H2]
-    float* __restrict__ W3s = sm + L.w3;   // [H2][LD3], columns >= C zero
+    float* __restrict__ W3T = sm + L.w3;   // [CW][LD3] = w3 transposed, classes >= C zero
     float* __restrict__ b3s = sm + L.b3;   // [CW]
     float* __restrict__ tgt = sm + L.tgt;  // [CW]
     float* __restrict__ xsb = sm + L.xs;   // 2 x [16][60] (+ pad): this step's rows / the next step's; rows 8..15 stay zero
-    float* __restrict__ h1s = sm + L.h1;   // [HS][16] unit-major, rows 8..15 stay zero
+    float* __restrict__ h1s = sm + L.h1;   // [16][LDH1] row-major, rows 8..15 stay zero
     float* __restrict__ d1s = sm + L.d1;   // [8][HS]
     float* __restrict__ h2s = sm + L.h2;   // [16][LD2], rows 8..15 stay zero
     float* __restrict__ d2s = sm + L.d2;   // [16][LD2], rows 8..15 stay zero
@@ -175,11 +175,11 @@ __global__ __launch_bounds__(kStepThreads) void step_kernel(StepArgs a)
     for (int e = tid; e < HS; e += kStepThreads) b1s[e] = P[off_b1 + i0 + e];
     for (int e = tid; e < HS * H2; e += kStepThreads) { const int i = e / H2, k = e - i * H2; W2s[i * LD2 + k] = P[off_w2 + (size_t)(i0 + i) * H2 + k]; }
     for (int e = tid; e < H2; e += kStepThreads) b2s[e] = P[off_b2 + e];
-    for (int e = tid; e < H2 * LD3; e += kStepThreads) { const int k = e / LD3, c = e - k * LD3; W3s[e] = c < C ? P[off_w3 + (size_t)k * C + c] : 0.0f; }
+    for (int e = tid; e < CW * H2; e += kStepThreads) { const int c = e / H2, k = e - c * H2; W3T[c * LD3 + k] = c < C ? P[off_w3 + (size_t)k * C + c] : 0.0f; }
     for (int e = tid; e < CW; e += kStepThreads) { b3s[e] = e < C ? P[off_b3 + e] : 0.0f; tgt[e] = e < C ? a.target[e] : 0.0f; }
     for (int e = tid; e < 16 * LD2; e += kStepThreads) { h2s[e] = 0.0f; d2s[e] = 0.0f; }
     for (int e = tid; e < 2 * kStepXs; e += kStepThreads) xsb[e] = 0.0f;
-    for (int e = tid; e < HS * LDH1; e += kStepThreads) h1s[e] = 0.0f;
+    for (int e = tid; e < 16 * LDH1; e += kStepThreads) h1s[e] = 0.0f;
     for (int e = tid; e < 4 * 16 * LDD3; e += kStepThreads) (sm + L.d3)[e] = 0.0f;
     if (tid < 17) ctl[tid] = 0;
 
@@ -262,7 +262,15 @@ __global__ __launch_bounds__(kStepThreads) void step_kernel(StepArgs a)
         for (int u = 0; u < TPWMAX; ++u) tt[u] = min(t0 + min(u, TPW - 1), NT - 1);
         STEP_MARK(0);
         // 1. own hidden-1 units: rows x units, K = inputs; wave w < 2 takes units [16 w, 16 w + 16).
-        // Result register v of lane (unit m16, g4) is row 4 g4 + v.
+        // Result register v of lane (unit m16, g4) is row 4 g4 + v.  Every wave also fetches its w2
+        // fragments of the next phase here, ahead of the barrier.  The contraction index of MFMA
+        // step st, lane group g4 in that phase is unit 16 (st / 4) + 4 g4 + st % 4: conflict-free
+        // reads of W2s, and 16-byte reads of the row-major h1.
+        float w2f[TPWMAX][HS / 4];
+#pragma unroll
+        for (int u = 0; u < TPWMAX; ++u)
+#pragma unroll
+            for (int st = 0; st < HS / 4; ++st) w2f[u][st] = W2s[(16 * (st >> 2) + 4 * g4 + (st & 3)) * LD2 + 16 * tt[u] + m16];
         if (wave < HS / 16) {
             const int ib = wave * 16;
             float av[IN / 4], bv[IN / 4];
@@ -282,30 +290,23 @@ __global__ __launch_bounds__(kStepThreads) void step_kernel(StepArgs a)
             acc = SZ_MFMA16(av[IN / 4 - 1], bv[IN / 4 - 1], acc);
             acc += acc2;
             if (g4 < 2) {
-                float4 o;
-                o.x = fmaxf(acc[0] + b, 0.0f); o.y = fmaxf(acc[1] + b, 0.0f);
-                o.z = fmaxf(acc[2] + b, 0.0f); o.w = fmaxf(acc[3] + b, 0.0f);
-                *reinterpret_cast<float4*>(h1s + (ib + m16) * LDH1 + 4 * g4) = o;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) h1s[(4 * g4 + v) * LDH1 + ib + m16] = fmaxf(acc[v] + b, 0.0f);
             }
         }
         __syncthreads();
         STEP_MARK(1);   // h1
-        // 2. partial second layer, own column tiles.  The contraction index of MFMA step st, lane
-        // group g4 is unit 16 (st / 4) + 4 g4 + st % 4 (conflict-free reads of W2s).
+        // 2. partial second layer, own column tiles
         {
-            float af[HS / 4], bf[TPWMAX][HS / 4];
+            f32x4 a4[HS / 16];
 #pragma unroll
-            for (int st = 0; st < HS / 4; ++st) af[st] = h1s[(16 * (st >> 2) + 4 * g4 + (st & 3)) * LDH1 + m16];
-#pragma unroll
-            for (int u = 0; u < TPWMAX; ++u)
-#pragma unroll
-                for (int st = 0; st < HS / 4; ++st) bf[u][st] = W2s[(16 * (st >> 2) + 4 * g4 + (st & 3)) * LD2 + 16 * tt[u] + m16];
+            for (int h = 0; h < HS / 16; ++h) a4[h] = *reinterpret_cast<const f32x4*>(h1s + m16 * LDH1 + 16 * h + 4 * g4);
             SZ_SCHED_FENCE();
             f32x4 acc[TPWMAX] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
             for (int st = 0; st < HS / 4; ++st)
 #pragma unroll
-                for (int u = 0; u < TPWMAX; ++u) acc[u] = SZ_MFMA16(af[st], bf[u][st], acc[u]);
+                for (int u = 0; u < TPWMAX; ++u) acc[u] = SZ_MFMA16(a4[st >> 2][st & 3], w2f[u][st], acc[u]);
             SZ_SCHED_FENCE();
             // slot layout [column][8 rows]: lane (column m16, g4 < 2) stores rows 4 g4 .. 4 g4 + 3 as 16 bytes
 #pragma unroll
@@ -381,19 +382,17 @@ __global__ __launch_bounds__(kStepThreads) void step_kernel(StepArgs a)
                 }
         }
         STEP_MARK(5);   // partials summed, tanh
-        // 5. logits = h2 . w3, K split over the waves by their own columns
+        // 5. logits = h2 . w3, K split over the waves by their own columns.  The contraction index of
+        // step q, lane group g4 within tile t is column 16 t + 4 g4 + q, so that a lane's four values
+        // are 16 contiguous bytes of h2 (row-major) and of w3 (transposed).
         {
-            float af[TPWMAX][4];
+            f32x4 af[TPWMAX];
 #pragma unroll
-            for (int u = 0; u < TPWMAX; ++u)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) af[u][q] = h2s[m16 * LD2 + 16 * tt[u] + 4 * q + g4];
+            for (int u = 0; u < TPWMAX; ++u) af[u] = *reinterpret_cast<const f32x4*>(h2s + m16 * LD2 + 16 * tt[u] + 4 * g4);
             for (int cb = 0; cb < CW; cb += 16) {
-                float bf[TPWMAX][4];
+                f32x4 bf[TPWMAX];
 #pragma unroll
-                for (int u = 0; u < TPWMAX; ++u)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) bf[u][q] = W3s[(16 * tt[u] + 4 * q + g4) * LD3 + cb + m16];
+                for (int u = 0; u < TPWMAX; ++u) bf[u] = *reinterpret_cast<const f32x4*>(W3T + (cb + m16) * LD3 + 16 * tt[u] + 4 * g4);
                 SZ_SCHED_FENCE();
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -413,6 +412,21 @@ __global__ __launch_bounds__(kStepThreads) void step_kernel(StepArgs a)
             }
         }
         if (wave == 0 && lane < kStepRows) ctl[8 * (cb_ ^ 1) + lane] = 0;  // live flags of the next step: cleared before they are set in 8.
+        // operands of 7. that do not depend on the softmax, fetched ahead of the barrier: w3 for
+        // delta2 (class 16 (st / 4) + 4 g4 + st % 4 in step st: conflict-free), h2 for its
+        // epilogue, and this wave's share of w2 for delta1 (16 bytes a lane, as in 5.)
+        float w3f[TPWMAX][kStepMaxC / 4], hv[TPWMAX][4];
+        f32x4 w2a[TPWMAX], w2b[TPWMAX];
+#pragma unroll
+        for (int u = 0; u < TPWMAX; ++u) {
+#pragma unroll
+            for (int st = 0; st < kStepMaxC / 4; ++st)
+                w3f[u][st] = 4 * st < CW ? W3T[(16 * (st >> 2) + 4 * g4 + (st & 3)) * LD3 + 16 * tt[u] + m16] : 0.0f;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) hv[u][v] = h2s[(4 * (g4 & 1) + v) * LD2 + 16 * tt[u] + m16];
+            w2a[u] = *reinterpret_cast<const f32x4*>(W2s + m16 * LD2 + 16 * tt[u] + 4 * g4);
+            w2b[u] = *reinterpret_cast<const f32x4*>(W2s + (16 + m16) * LD2 + 16 * tt[u] + 4 * g4);
+        }
         __syncthreads();
         STEP_MARK(6);   // logits
         // 6. every wave for itself: softmax, loss with the pre-update weights, delta3 = o - t
@@ -433,11 +447,11 @@ __global__ __launch_bounds__(kStepThreads) void step_kernel(StepArgs a)
             mx = fmaxf(mx, dpp16<0xB1>(mx)); mx = fmaxf(mx, dpp16<0x4E>(mx));
             mx = fmaxf(mx, dpp16<0x141>(mx)); mx = fmaxf(mx, dpp16<0x140>(mx));
             if (CW > 16) mx = fmaxf(mx, __shfl_xor(mx, 16));
-            const float ex = cls ? expf(z - mx) : 0.0f;
+            const float ex = cls ? __expf(z - mx) : 0.0f;
             float sum = ex;
             sum += dpp16<0xB1>(sum); sum += dpp16<0x4E>(sum); sum += dpp16<0x141>(sum); sum += dpp16<0x140>(sum);
             if (CW > 16) sum += __shfl_xor(sum, 16);
-            const float o = ex / sum, t = tgt[c];
+            const float o = ex * __builtin_amdgcn_rcpf(sum), t = tgt[c];
             if (wave == 0) {
                 if (cls && alive && t != 0.0f) loss_acc -= (double)(t * logf(fmaxf(o, 1e-12f)));
                 if (c == 0 && alive) live_acc += 1.0;
@@ -448,24 +462,17 @@ __global__ __launch_bounds__(kStepThreads) void step_kernel(StepArgs a)
         // 7. still every wave for itself, on its own columns.  delta2 = (delta3 . w3^T)(1 - h2^2),
         // lib.rs:1034: rows x columns of h2, K = classes.
         {
-            float af[kStepMaxC / 4];  // delta3[row m16][class 4 st + g4]
-            float bf[TPWMAX][kStepMaxC / 4], hv[TPWMAX][4];
+            f32x4 a4[kStepMaxC / 16];  // delta3[row m16][class 16 h + 4 g4 + 0..3]
 #pragma unroll
-            for (int st = 0; st < kStepMaxC / 4; ++st) af[st] = 4 * st < CW ? d3w[m16 * LDD3 + 4 * st + g4] : 0.0f;
-#pragma unroll
-            for (int u = 0; u < TPWMAX; ++u) {
-#pragma unroll
-                for (int st = 0; st < kStepMaxC / 4; ++st) bf[u][st] = 4 * st < CW ? W3s[(16 * tt[u] + m16) * LD3 + 4 * st + g4] : 0.0f;
-#pragma unroll
-                for (int v = 0; v < 4; ++v) hv[u][v] = h2s[(4 * (g4 & 1) + v) * LD2 + 16 * tt[u] + m16];
-            }
+            for (int h = 0; h < kStepMaxC / 16; ++h)
+                a4[h] = 16 * h < CW ? *reinterpret_cast<const f32x4*>(d3w + m16 * LDD3 + 16 * h + 4 * g4) : f32x4{0.f, 0.f, 0.f, 0.f};
             SZ_SCHED_FENCE();
             f32x4 acc[TPWMAX] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
             for (int st = 0; st < kStepMaxC / 4; ++st)
                 if (4 * st < CW) {
 #pragma unroll
-                    for (int u = 0; u < TPWMAX; ++u) acc[u] = SZ_MFMA16(af[st], bf[u][st], acc[u]);
+                    for (int u = 0; u < TPWMAX; ++u) acc[u] = SZ_MFMA16(a4[st >> 2][st & 3], w3f[u][st], acc[u]);
                 }
             SZ_SCHED_FENCE();
 #pragma unroll
@@ -477,68 +484,89 @@ __global__ __launch_bounds__(kStepThreads) void step_kernel(StepArgs a)
         }
         STEP_MARK(8);   // delta2
         if (n_live > 0) {
-            // delta1 of the own units, delta2 . w2[own, :]^T with the old w2: this wave's share of K
-            // (its own columns), two tiles of 16 units
-            {
-                static_assert(kStepHS == 32, "two tiles of 16 units");
-                float dv[TPWMAX][4], w0[TPWMAX][4], w1[TPWMAX][4];
+            // Reads of everything the rest of 7. needs, then its matrix instructions back to back:
+            //   delta1 of the own units, delta2 . w2[own, :]^T with the old w2: this wave's share of K
+            //     (its own columns), two tiles of 16 units;
+            //   dW3 = h2^T . delta3 for the own rows of w3 (rows of w3 x classes, K = the 8 rows):
+            //     register v of lane (class m16, g4) is row 16 t + 4 g4 + v, 16 contiguous bytes of W3T;
+            //   dW2^T = delta2^T . h1 for the own columns (columns x units, K = the 8 rows): register v
+            //     of lane (unit m16, g4) is column 16 t + 4 g4 + v, 16 contiguous bytes of a W2s row.
+            static_assert(kStepHS == 32, "two tiles of 16 units");
+            f32x4 dv[TPWMAX];
+            float d3f[kStepMaxC / 16][kStepRows / 4], hf[TPWMAX][kStepRows / 4], h1f[2][kStepRows / 4], d2f[TPWMAX][kStepRows / 4];
+            f32x4 w3o[kStepMaxC / 16][TPWMAX];
+            f32x4 w2o[TPWMAX][2];
 #pragma unroll
-                for (int u = 0; u < TPWMAX; ++u)
+            for (int u = 0; u < TPWMAX; ++u) dv[u] = *reinterpret_cast<const f32x4*>(d2s + m16 * LD2 + 16 * tt[u] + 4 * g4);
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int k = 16 * tt[u] + 4 * q + g4;
-                        dv[u][q] = d2s[m16 * LD2 + k];
-                        w0[u][q] = W2s[m16 * LD2 + k];
-                        w1[u][q] = W2s[(16 + m16) * LD2 + k];
-                    }
-                SZ_SCHED_FENCE();
-                f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+            for (int st = 0; st < kStepRows / 4; ++st) {
 #pragma unroll
-                for (int u = 0; u < TPWMAX; ++u)
-                    if (u < ntw) {
+                for (int h = 0; h < kStepMaxC / 16; ++h) d3f[h][st] = 16 * h < CW ? d3w[(4 * st + g4) * LDD3 + 16 * h + m16] : 0.0f;
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            acc0 = SZ_MFMA16(dv[u][q], w0[u][q], acc0);
-                            acc1 = SZ_MFMA16(dv[u][q], w1[u][q], acc1);
-                        }
-                    }
-                SZ_SCHED_FENCE();
-                if (g4 < 2) {
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) {
-                        red2[((size_t)wave * kStepRows + 4 * g4 + v) * HS + m16] = acc0[v];
-                        red2[((size_t)wave * kStepRows + 4 * g4 + v) * HS + 16 + m16] = acc1[v];
-                    }
-                }
-            }
-            STEP_MARK(9);   // delta1 parts
-            // replicated output layer, own rows of w3: dW3 = h2^T . delta3 (rows of w3 x classes, K = the 8
-            // rows); register v of lane (class m16, g4) is row 16 t + 4 g4 + v
-            for (int cb = 0; cb < CW; cb += 16) {
-                float bf[kStepRows / 4], hf[TPWMAX][kStepRows / 4], wv[TPWMAX][4];
-#pragma unroll
-                for (int st = 0; st < kStepRows / 4; ++st) bf[st] = d3w[(4 * st + g4) * LDD3 + cb + m16];
+                for (int ib = 0; ib < 2; ++ib) h1f[ib][st] = h1s[(4 * st + g4) * LDH1 + 16 * ib + m16];
 #pragma unroll
                 for (int u = 0; u < TPWMAX; ++u) {
-#pragma unroll
-                    for (int st = 0; st < kStepRows / 4; ++st) hf[u][st] = h2s[(4 * st + g4) * LD2 + 16 * tt[u] + m16];
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) wv[u][v] = W3s[(16 * tt[u] + 4 * g4 + v) * LD3 + cb + m16];
+                    hf[u][st] = h2s[(4 * st + g4) * LD2 + 16 * tt[u] + m16];
+                    d2f[u][st] = d2s[(4 * st + g4) * LD2 + 16 * tt[u] + m16];
                 }
-                SZ_SCHED_FENCE();
-                f32x4 acc[TPWMAX] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+            }
 #pragma unroll
-                for (int st = 0; st < kStepRows / 4; ++st)
+            for (int u = 0; u < TPWMAX; ++u) {
 #pragma unroll
-                    for (int u = 0; u < TPWMAX; ++u) acc[u] = SZ_MFMA16(hf[u][st], bf[st], acc[u]);
-                SZ_SCHED_FENCE();
+                for (int h = 0; h < kStepMaxC / 16; ++h)
+                    w3o[h][u] = 16 * h < CW ? *reinterpret_cast<const f32x4*>(W3T + (16 * h + m16) * LD3 + 16 * tt[u] + 4 * g4) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ib = 0; ib < 2; ++ib) w2o[u][ib] = *reinterpret_cast<const f32x4*>(W2s + (16 * ib + m16) * LD2 + 16 * tt[u] + 4 * g4);
+            }
+            SZ_SCHED_FENCE();
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < TPWMAX; ++u)
+                if (u < ntw) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        acc0 = SZ_MFMA16(dv[u][q], w2a[u][q], acc0);
+                        acc1 = SZ_MFMA16(dv[u][q], w2b[u][q], acc1);
+                    }
+                }
+            f32x4 acc3[kStepMaxC / 16][TPWMAX], acc2[TPWMAX][2];
+#pragma unroll
+            for (int h = 0; h < kStepMaxC / 16; ++h)
+                if (16 * h < CW) {
+#pragma unroll
+                    for (int u = 0; u < TPWMAX; ++u) acc3[h][u] = SZ_MFMA16(hf[u][0], d3f[h][0], (f32x4{0.f, 0.f, 0.f, 0.f}));
+#pragma unroll
+                    for (int u = 0; u < TPWMAX; ++u) acc3[h][u] = SZ_MFMA16(hf[u][1], d3f[h][1], acc3[h][u]);
+                }
+#pragma unroll
+            for (int u = 0; u < TPWMAX; ++u)
+#pragma unroll
+                for (int ib = 0; ib < 2; ++ib) acc2[u][ib] = SZ_MFMA16(d2f[u][0], h1f[ib][0], (f32x4{0.f, 0.f, 0.f, 0.f}));
+#pragma unroll
+            for (int u = 0; u < TPWMAX; ++u)
+#pragma unroll
+                for (int ib = 0; ib < 2; ++ib) acc2[u][ib] = SZ_MFMA16(d2f[u][1], h1f[ib][1], acc2[u][ib]);
+            SZ_SCHED_FENCE();
+            if (g4 < 2) {
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    red2[((size_t)wave * kStepRows + 4 * g4 + v) * HS + m16] = acc0[v];
+                    red2[((size_t)wave * kStepRows + 4 * g4 + v) * HS + 16 + m16] = acc1[v];
+                }
+            }
+#pragma unroll
+            for (int h = 0; h < kStepMaxC / 16; ++h)
 #pragma unroll
                 for (int u = 0; u < TPWMAX; ++u)
-                    if (cb + m16 < C && u < ntw) {
+                    if (16 * h < CW && 16 * h + m16 < C && u < ntw)
+                        *reinterpret_cast<f32x4*>(W3T + (16 * h + m16) * LD3 + 16 * tt[u] + 4 * g4) = w3o[h][u] - scale * acc3[h][u];
 #pragma unroll
-                        for (int v = 0; v < 4; ++v) W3s[(16 * tt[u] + 4 * g4 + v) * LD3 + cb + m16] = wv[u][v] - scale * acc[u][v];
-                    }
-            }
+            for (int u = 0; u < TPWMAX; ++u)
+                if (u < ntw) {
+#pragma unroll
+                    for (int ib = 0; ib < 2; ++ib)
+                        *reinterpret_cast<f32x4*>(W2s + (16 * ib + m16) * LD2 + 16 * tt[u] + 4 * g4) = w2o[u][ib] - scale * acc2[u][ib];
+                }
             if (lane < 16 * ntw) {   // b2 of the own columns
                 const int k = 16 * t0 + lane;
                 float g2 = 0.0f;
@@ -552,65 +580,24 @@ __global__ __launch_bounds__(kStepThreads) void step_kernel(StepArgs a)
                 for (int r = 0; r < kStepRows; ++r) g += d3w[r * LDD3 + lane];
                 b3s[lane] -= scale * g;
             }
-            STEP_MARK(10);  // dW3, b2, b3
-            // own rows of w2, own columns: -= scale * h1^T . delta2 (units x columns, K = the 8 rows);
-            // register v of lane (column m16, g4) is unit 16 ib + 4 g4 + v
-            {
-                float af[2][kStepRows / 4];  // h1[row 4 st + g4][unit 16 ib + m16]
-                float b0[TPWMAX], b1[TPWMAX], wv[TPWMAX][2][4];
-#pragma unroll
-                for (int ib = 0; ib < 2; ++ib)
-#pragma unroll
-                    for (int st = 0; st < kStepRows / 4; ++st) af[ib][st] = h1s[(16 * ib + m16) * LDH1 + 4 * st + g4];
-#pragma unroll
-                for (int u = 0; u < TPWMAX; ++u) {
-                    b0[u] = d2s[g4 * LD2 + 16 * tt[u] + m16];
-                    b1[u] = d2s[(4 + g4) * LD2 + 16 * tt[u] + m16];
-#pragma unroll
-                    for (int ib = 0; ib < 2; ++ib)
-#pragma unroll
-                        for (int v = 0; v < 4; ++v) wv[u][ib][v] = W2s[(16 * ib + 4 * g4 + v) * LD2 + 16 * tt[u] + m16];
-                }
-                SZ_SCHED_FENCE();
-                f32x4 acc[TPWMAX][2];
-#pragma unroll
-                for (int u = 0; u < TPWMAX; ++u)
-#pragma unroll
-                    for (int ib = 0; ib < 2; ++ib) acc[u][ib] = SZ_MFMA16(af[ib][0], b0[u], (f32x4{0.f, 0.f, 0.f, 0.f}));
-#pragma unroll
-                for (int u = 0; u < TPWMAX; ++u)
-#pragma unroll
-                    for (int ib = 0; ib < 2; ++ib) acc[u][ib] = SZ_MFMA16(af[ib][1], b1[u], acc[u][ib]);
-                SZ_SCHED_FENCE();
-#pragma unroll
-                for (int u = 0; u < TPWMAX; ++u)
-                    if (u < ntw) {
-#pragma unroll
-                        for (int ib = 0; ib < 2; ++ib)
-#pragma unroll
-                            for (int v = 0; v < 4; ++v) W2s[(16 * ib + 4 * g4 + v) * LD2 + 16 * tt[u] + m16] = wv[u][ib][v] - scale * acc[u][ib][v];
-                    }
-            }
             __syncthreads();
             STEP_MARK(11);  // w2 update
-            // 8. delta1: every wave combines all the waves' parts (the same sums, the same writes),
-            // ReLU derivative (lib.rs:1039-1040)
-#pragma unroll
-            for (int q = 0; q < kStepRows * HS / 64; ++q) {
-                const int e = lane + 64 * q, r = e / HS, i = e - r * HS;
-                const float s = (red2[(0 * kStepRows + r) * HS + i] + red2[(1 * kStepRows + r) * HS + i]) +
-                                (red2[(2 * kStepRows + r) * HS + i] + red2[(3 * kStepRows + r) * HS + i]);
-                d1s[r * HS + i] = h1s[i * LDH1 + r] > 0.0f ? s : 0.0f;
-            }
-            // own columns of w1 -= scale * x^T . delta1 (inputs x units, K = the 8 rows), own b1;
-            // wave w takes inputs [16 w, 16 w + 16) (inputs past 59 read the next row's start: finite, dropped)
+            // 8. delta1[row 4 st + g4][unit 16 ib + m16], the operand of dW1: every lane sums the four
+            // waves' parts of its elements (the same order everywhere) and applies the ReLU derivative
+            // (lib.rs:1039-1040).  Own columns of w1 -= scale * x^T . delta1 (inputs x units, K = the 8
+            // rows); wave w takes inputs [16 w, 16 w + 16) (inputs past 59 read the next row's start:
+            // finite, dropped).  b1 -= scale * column sums of delta1.
             {
-                float bf[2][kStepRows / 4];  // delta1[row 4 st + g4][unit 16 ib + m16]
-                float wv[2][4];
+                float bf[2][kStepRows / 4], wv[2][4];
+                float p[2][kStepRows / 4][4], hm[2][kStepRows / 4];
 #pragma unroll
                 for (int ib = 0; ib < 2; ++ib)
 #pragma unroll
-                    for (int st = 0; st < kStepRows / 4; ++st) bf[ib][st] = d1s[(4 * st + g4) * HS + 16 * ib + m16];
+                    for (int st = 0; st < kStepRows / 4; ++st) {
+#pragma unroll
+                        for (int w = 0; w < 4; ++w) p[ib][st][w] = red2[((size_t)w * kStepRows + 4 * st + g4) * HS + 16 * ib + m16];
+                        hm[ib][st] = h1s[(4 * st + g4) * LDH1 + 16 * ib + m16];
+                    }
                 const int j = 16 * wave + m16;
                 const float a0 = xs[g4 * IN + j], a1 = xs[(4 + g4) * IN + j];
 #pragma unroll
@@ -618,11 +605,27 @@ __global__ __launch_bounds__(kStepThreads) void step_kernel(StepArgs a)
 #pragma unroll
                     for (int v = 0; v < 4; ++v) wv[ib][v] = W1s[min(16 * wave + 4 * g4 + v, IN - 1) * LDW1 + 16 * ib + m16];
                 SZ_SCHED_FENCE();
+#pragma unroll
+                for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+                    for (int st = 0; st < kStepRows / 4; ++st) {
+                        const float sum = (p[ib][st][0] + p[ib][st][1]) + (p[ib][st][2] + p[ib][st][3]);
+                        bf[ib][st] = hm[ib][st] > 0.0f ? sum : 0.0f;
+                    }
                 f32x4 acc[2];
 #pragma unroll
                 for (int ib = 0; ib < 2; ++ib) acc[ib] = SZ_MFMA16(a0, bf[ib][0], (f32x4{0.f, 0.f, 0.f, 0.f}));
 #pragma unroll
                 for (int ib = 0; ib < 2; ++ib) acc[ib] = SZ_MFMA16(a1, bf[ib][1], acc[ib]);
+                if (wave == 0) {   // b1: rows g4 and 4 + g4 of a unit sit in this lane, the other rows 16 lanes apart
+#pragma unroll
+                    for (int ib = 0; ib < 2; ++ib) {
+                        float g = bf[ib][0] + bf[ib][1];
+                        g += __shfl_xor(g, 16);
+                        g += __shfl_xor(g, 32);
+                        if (g4 == 0) b1s[16 * ib + m16] -= scale * g;
+                    }
+                }
                 SZ_SCHED_FENCE();
 #pragma unroll
                 for (int ib = 0; ib < 2; ++ib)
@@ -631,12 +634,6 @@ __global__ __launch_bounds__(kStepThreads) void step_kernel(StepArgs a)
                         const int jj = 16 * wave + 4 * g4 + v;
                         if (jj < IN) W1s[jj * LDW1 + 16 * ib + m16] = wv[ib][v] - scale * acc[ib][v];
                     }
-            }
-            if (wave == 0 && lane < HS) {
-                float g = 0.0f;
-#pragma unroll
-                for (int r = 0; r < kStepRows; ++r) g += d1s[r * HS + lane];
-                b1s[lane] -= scale * g;
             }
         }
         // the next step's rows (fetched during the exchange) -> the other LDS buffer
@@ -656,7 +653,7 @@ __global__ __launch_bounds__(kStepThreads) void step_kernel(StepArgs a)
     for (int e = tid; e < HS * H2; e += kStepThreads) { const int i = e / H2, k = e - i * H2; Pw[off_w2 + (size_t)(i0 + i) * H2 + k] = W2s[i * LD2 + k]; }
     if (blk == 0) {
         for (int e = tid; e < H2; e += kStepThreads) Pw[off_b2 + e] = b2s[e];
-        for (int e = tid; e < H2 * C; e += kStepThreads) { const int k = e / C, c = e - k * C; Pw[off_w3 + e] = W3s[k * LD3 + c]; }
+        for (int e = tid; e < H2 * C; e += kStepThreads) { const int k = e / C, c = e - k * C; Pw[off_w3 + e] = W3T[c * LD3 + k]; }
         for (int e = tid; e < C; e += kStepThreads) Pw[off_b3 + e] = b3s[e];
         // per-lane sums of wave 0 -> one add per lane that saw a loss term
         if (loss_acc != 0.0) atomicAdd(&a.totals[0], loss_acc);
