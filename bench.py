@@ -155,9 +155,10 @@ def other_figures(sz, ext, plan, pcm, feats, net_dims, n_win, dev, lr, dropout):
     n_b8 = min(n_win, 6614)
     host = feats[:n_b8].cpu().numpy()
     sz.pretrain_from_features(net, host[:64], 1, net_dims[3], 1, lr, dropout, 8, seed=1)  # warm
+    b8_epochs = 10
     t0 = time.perf_counter()
-    sz.pretrain_from_features(net, host, 1, net_dims[3], 1, lr, dropout, 8, seed=2)
-    t_b8 = time.perf_counter() - t0
+    sz.pretrain_from_features(net, host, 1, net_dims[3], b8_epochs, lr, dropout, 8, seed=2)
+    t_b8 = (time.perf_counter() - t0) / b8_epochs
     # the inference-only configuration: a 100 h recording (39 689 999 windows) already in device
     # memory, identify_speaker_list in tiles of 8192 windows replayed from a HIP graph
     n_stream = 100 * 3600 * 44100
@@ -178,7 +179,8 @@ def other_figures(sz, ext, plan, pcm, feats, net_dims, n_win, dev, lr, dropout):
             "infer_windows_per_s": n_win / t_inf,
             "infer_note": "extract + forward + thresholded vote (lib.rs:1383-1411) over all clips, device-resident",
             "cli_batch8_train_windows_per_s": n_b8 / t_b8,
-            "cli_batch8_note": f"pretrain_from_features, batch 8, dropout {dropout:g}, one epoch of {n_b8} windows through the host API"}
+            "cli_batch8_note": f"pretrain_from_features, batch 8, dropout {dropout:g}, {b8_epochs} epochs of {n_b8} windows in one call "
+                               "through the host API (the CLI runs 100 per file), wall time of the call"}
 
 
 def main():
@@ -363,7 +365,7 @@ def main():
         out["other_figures"] = other_figures(sz, ext, plan, pcm, feats, (60, H1, H2, C), n_win, dev, args.lr, args.dropout)
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.speakers, (H1, H2), args.seconds)
-    print(json.dumps(out))
+    print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 
