@@ -223,8 +223,10 @@ int szh_extract_embedding(szh_net *net, szh_extractor *ext, const int16_t *pcm, 
 
 /* identify_speaker, lib.rs:1285-1303: the class whose window probabilities sum highest (the last
  * maximum wins; 0 for a net without outputs).  sums (optional, output_size entries) receives the
- * per-class sums.  They are accumulated in f64 on the device and compared as f32; the reference
- * adds f32 values in window order, so a decision can differ only where its own rounding decides. */
+ * per-class sums.  Sums and window counts are exact in f64 on the device and compared as f32; the
+ * reference adds f32 values in window order (and its f32 window count stops at 2^24), so a decision
+ * can differ only where the reference's own rounding decides.  Training calls and the *_dev calls on
+ * one net must be serialised by the caller; *_dev calls need the handle's device current. */
 int szh_identify_speaker(szh_net *net, szh_extractor *ext, const int16_t *pcm, uint64_t n_samples, uint32_t *id,
                          float *sums);
 /* identify_speaker_with_threshold, lib.rs:1307-1343: *id = the arg-max of the sums if

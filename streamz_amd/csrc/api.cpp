@@ -543,6 +543,7 @@ int szh_plan_window_offsets(const szh_plan* plan, uint64_t* out)
 int szh_plan_run_dev(szh_plan* plan, const int16_t* pcm_dev, float* feats_dev, void* stream)
 {
     if (!plan || !pcm_dev || !feats_dev) { set_error("null argument"); return SZH_EINVAL; }
+    { int cur = -1; SZ_HIP(hipGetDevice(&cur)); if (cur != reinterpret_cast<Plan*>(plan)->ext->device) { set_error("plan belongs to device %d but the current device is %d", reinterpret_cast<Plan*>(plan)->ext->device, cur); return SZH_EINVAL; } }
     return plan_run(reinterpret_cast<Plan*>(plan), pcm_dev, feats_dev, static_cast<hipStream_t>(stream));
 }
 
@@ -833,8 +834,10 @@ static uint32_t host_tile(uint64_t nw)
 }
 
 // The reference's decision on per-class probability sums (lib.rs:1298-1302, 1332-1342): the
-// sums are compared as f32, the last maximum wins; `count` is the f32 the reference counts
-// windows in, which stops growing at 2^24.
+// sums are compared as f32, the last maximum wins.  The reference adds the probabilities and
+// counts the windows sequentially in f32 (its count stops growing at 2^24 windows, 42 h of
+// audio); here both are exact in f64 on purpose -- a parallel sum cannot reproduce a sequential
+// f32 rounding order, and the mean of a recording longer than that stays a mean.
 static uint32_t best_of_sums(const std::vector<double>& sums, float* sums_out)
 {
     uint32_t best = 0;
@@ -848,8 +851,7 @@ static int64_t thresholded(const std::vector<double>& sums, uint64_t n_windows, 
 {
     const uint32_t best = best_of_sums(sums, sums_out);
     if (sums.size() <= 1 || n_windows == 0) return -1;  // lib.rs:1316-1318, 1329-1331
-    const float count = (float)std::min<uint64_t>(n_windows, 1ull << 24);
-    return (float)sums[best] / count >= threshold ? (int64_t)best : -1;
+    return (float)(sums[best] / (double)n_windows) >= threshold ? (int64_t)best : -1;
 }
 
 int szh_identify_speaker_list(szh_net* net, szh_extractor* ext, const int16_t* pcm, uint64_t n_samples,
@@ -928,12 +930,25 @@ int szh_identify_speaker_list_dev(szh_net* net, szh_extractor* ext, const int16_
 }
 
 // ---- device-resident building blocks ----------------------------------------------------
+// These calls enqueue work with pointers of the device the handle was created on: the calling
+// thread must have that device current (szh_init), or the kernels would run elsewhere.
+static int check_device(int handle_device)
+{
+    int cur = -1;
+    SZ_HIP(hipGetDevice(&cur));
+    if (cur != handle_device) {
+        set_error("handle belongs to device %d but the calling thread's current device is %d (call szh_init first)", handle_device, cur);
+        return SZH_EINVAL;
+    }
+    return SZH_OK;
+}
 
 uint64_t szh_net_grad_len(const szh_net* net) { return net ? reinterpret_cast<const Net*>(net)->param_count() + 2 : 0; }
 float* szh_net_grad_dev(szh_net* net) { return net ? reinterpret_cast<Net*>(net)->d_grad : nullptr; }
 int szh_net_zero_grad_dev(szh_net* net, void* stream)
 {
     if (!net) { set_error("null argument"); return SZH_EINVAL; }
+    if (int rc = check_device(reinterpret_cast<Net*>(net)->device)) return rc;
     return net_zero_grad(reinterpret_cast<Net*>(net), static_cast<hipStream_t>(stream));
 }
 int szh_net_accumulate_dev(szh_net* net, const float* feats_dev, const int32_t* labels_dev, uint64_t n, float dropout,
@@ -941,6 +956,7 @@ int szh_net_accumulate_dev(szh_net* net, const float* feats_dev, const int32_t* 
 {
     SZ_TRY
     if (!net || (n && (!feats_dev || !labels_dev))) { set_error("null argument"); return SZH_EINVAL; }
+    if (int rc = check_device(reinterpret_cast<Net*>(net)->device)) return rc;
     AccumArgs a;
     a.x_dev = feats_dev;
     a.rows = n;
@@ -954,12 +970,14 @@ int szh_net_accumulate_dev(szh_net* net, const float* feats_dev, const int32_t* 
 int szh_net_apply_grad_dev(szh_net* net, float lr, void* stream)
 {
     if (!net) { set_error("null argument"); return SZH_EINVAL; }
+    if (int rc = check_device(reinterpret_cast<Net*>(net)->device)) return rc;
     return net_apply(reinterpret_cast<Net*>(net), lr, static_cast<hipStream_t>(stream));
 }
 int szh_net_forward_dev(szh_net* net, const float* feats_dev, uint64_t n, float* probs_dev, void* stream)
 {
     SZ_TRY
     if (!net || (n && (!feats_dev || !probs_dev))) { set_error("null argument"); return SZH_EINVAL; }
+    if (int rc = check_device(reinterpret_cast<Net*>(net)->device)) return rc;
     return net_forward_dev(reinterpret_cast<Net*>(net), feats_dev, n, probs_dev, kFwdProbs, static_cast<hipStream_t>(stream));
     SZ_CATCH
 }
@@ -968,6 +986,7 @@ int szh_net_vote_dev(szh_net* net, const float* feats_dev, uint64_t n, float thr
 {
     SZ_TRY
     if (!net || (n && (!feats_dev || !counts_dev))) { set_error("null argument"); return SZH_EINVAL; }
+    if (int rc = check_device(reinterpret_cast<Net*>(net)->device)) return rc;
     return net_vote_dev(reinterpret_cast<Net*>(net), feats_dev, n, threshold, counts_dev, nullptr, static_cast<hipStream_t>(stream));
     SZ_CATCH
 }
@@ -1108,7 +1127,10 @@ int szh_net_load(const char* path, szh_net** net)
                    *b2 = need("b2", "<f4", 1), *sr = need("sample_rate", "<i8", 1), *bits = need("bits", "<i8", 1);
     if (!w1 || !b1 || !w2 || !b2 || !sr || !bits) return SZH_EIO;
     const uint32_t in = (uint32_t)w1->shape[0], h1 = (uint32_t)w1->shape[1], h2 = (uint32_t)w2->shape[1];
-    if (w2->shape[0] != h1 || b1->shape[0] != h1 || b2->shape[0] != h2 || sr->count() < 1 || bits->count() < 1) {
+    if (w1->shape[0] == 0 || w1->shape[0] > 0xffffffffull || w1->shape[1] == 0 || w1->shape[1] > 0xffffffffull ||
+        w2->shape[1] == 0 || w2->shape[1] > 0xffffffffull || w2->shape[0] != h1 || b1->shape[0] != h1 || b2->shape[0] != h2 ||
+        w1->data.size() != (size_t)in * h1 * 4 || b1->data.size() != (size_t)h1 * 4 || w2->data.size() != (size_t)h1 * h2 * 4 ||
+        b2->data.size() != (size_t)h2 * 4 || sr->count() < 1 || bits->count() < 1) {
         set_error("%s: inconsistent layer shapes", path);
         return SZH_EIO;
     }
@@ -1218,7 +1240,13 @@ int szh_load_cached_features(const char* path, szh_extractor* ext, float** feats
     if (file_exists(cache)) {  // lib.rs:563-570
         NpyArray a;
         if (!npy_read_file(cache, a, err)) { set_error("%s", err.c_str()); return SZH_EIO; }
-        if (a.descr != "<f4" || a.shape.size() != 2 || a.fortran_order) { set_error("%s: not a C-order 2-D float32 array", cache.c_str()); return SZH_EIO; }
+        // the reference's read_npy into Array2<f32> takes any (n, m); its consumers then fail on rows that
+        // are not 60 wide.  Here the mismatch is reported at once instead of handing out a short buffer.
+        if (a.descr != "<f4" || a.shape.size() != 2 || a.fortran_order || a.shape[1] != (uint64_t)kFeat ||
+            a.data.size() != a.shape[0] * (uint64_t)kFeat * sizeof(float)) {
+            set_error("%s: not a C-order (n, %d) float32 array", cache.c_str(), kFeat);
+            return SZH_EFORMAT;
+        }
         float* out = static_cast<float*>(std::malloc(a.data.size() ? a.data.size() : 4));
         if (!out) { set_error("out of host memory"); return SZH_ENOMEM; }
         std::memcpy(out, a.data.data(), a.data.size());

@@ -106,8 +106,13 @@ bool npy_parse(const uint8_t* buf, size_t len, NpyArray& out, std::string& err)
     size_t item = 0;
     if (out.descr.size() >= 3) item = (size_t)std::atoi(out.descr.c_str() + 2);
     if (item == 0) { err = "unsupported NPY dtype " + out.descr; return false; }
-    const size_t need = (size_t)out.count() * item;
-    if (hoff + hlen + need > len) { err = "truncated NPY payload"; return false; }
+    // the element count and the byte size are multiplied out with an overflow check: a header can claim any shape
+    uint64_t need = item;
+    for (uint64_t d : out.shape) {
+        if (d != 0 && need > UINT64_MAX / d) { err = "NPY shape overflows"; return false; }
+        need *= d;
+    }
+    if (need > len || hoff + hlen > len - need) { err = "truncated NPY payload"; return false; }
     out.data.assign(buf + hoff + hlen, buf + hoff + hlen + need);
     return true;
 }

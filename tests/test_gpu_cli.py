@@ -124,6 +124,21 @@ def test_load_cached_features_miss_then_hit(sz, tmp_path, monkeypatch):
     assert not os.path.exists(os.path.join("feature_cache", "data_short.wav.npy"))
     with pytest.raises(sz.StreamzError):
         sz.load_cached_features("data/absent.wav", ext)
+    # a stale or foreign cache file whose rows are not 60 wide, or that claims more rows than it holds,
+    # is refused rather than read past its end
+    np.save(cache, np.zeros((7, 40), np.float32))
+    with pytest.raises(sz.StreamzError) as ei:
+        sz.load_cached_features("data/clip.wav", ext)
+    assert ei.value.code == -5
+    np.save(cache, direct)
+    raw = bytearray(open(cache, "rb").read())
+    hdr = bytes(raw).index(b"'shape': (") + len("'shape': (")
+    digits = str(direct.shape[0]).encode()
+    assert bytes(raw[hdr:hdr + len(digits)]) == digits
+    raw[hdr:hdr + len(digits)] = b"9" * len(digits)          # same header length, more rows claimed
+    open(cache, "wb").write(bytes(raw))
+    with pytest.raises(sz.StreamzError):
+        sz.load_cached_features("data/clip.wav", ext)
 
 
 def test_cli_trains_ten_clips_two_speakers(sz, tmp_path):
