@@ -100,22 +100,52 @@ int extract_files_host(Extractor* e, const int16_t* const* pcm, const uint64_t* 
     return SZH_OK;
 }
 
+// Host rows -> the net's device staging buffer `slot`.  Small inputs travel through the net's pinned
+// buffer as an asynchronous copy (a pageable hipMemcpy of a few hundred bytes costs more than the
+// kernels of a one-row forward).
+constexpr size_t kPinnedLimit = 1 << 20;
+int stage_in(Net* n, int slot, const void* host, size_t bytes, size_t pinned_off, void** dev)
+{
+    int rc = net_stage_dev(n, slot, bytes, dev);
+    if (rc) return rc;
+    if (pinned_off + bytes <= kPinnedLimit) {
+        void* pin = nullptr;
+        rc = net_stage_pinned(n, kPinnedLimit, &pin);
+        if (rc) return rc;
+        std::memcpy(static_cast<char*>(pin) + pinned_off, host, bytes);
+        SZ_HIP(hipMemcpyAsync(*dev, static_cast<char*>(pin) + pinned_off, bytes, hipMemcpyHostToDevice, nullptr));
+    } else {
+        SZ_HIP(hipMemcpy(*dev, host, bytes, hipMemcpyHostToDevice));
+    }
+    return SZH_OK;
+}
+
 int forward_host(Net* n, const float* x, uint64_t B, float* out, ForwardKind kind)
 {
     if (B == 0) return SZH_OK;
     const uint32_t ow = kind == kFwdProbs ? n->out : n->h2;
     if (ow == 0) return SZH_OK;
     std::lock_guard<std::mutex> lock(n->mu);
-    DevBuf dx, dout;
-    int rc = dx.alloc(B * n->in * sizeof(float));
+    const size_t in_bytes = B * n->in * sizeof(float), out_bytes = B * ow * sizeof(float);
+    void *dx = nullptr, *dout = nullptr;
+    int rc = stage_in(n, 0, x, in_bytes, 0, &dx);
     if (rc) return rc;
-    rc = dout.alloc(B * ow * sizeof(float));
+    rc = net_stage_dev(n, 1, out_bytes, &dout);
     if (rc) return rc;
-    SZ_HIP(hipMemcpy(dx.p, x, B * n->in * sizeof(float), hipMemcpyHostToDevice));
-    rc = net_forward_dev(n, dx.as<float>(), B, dout.as<float>(), kind, nullptr);
+    rc = net_forward_dev(n, static_cast<const float*>(dx), B, static_cast<float*>(dout), kind, nullptr);
     if (rc) return rc;
-    SZ_HIP(hipStreamSynchronize(nullptr));
-    SZ_HIP(hipMemcpy(out, dout.p, B * ow * sizeof(float), hipMemcpyDeviceToHost));
+    const size_t in_pin = (in_bytes + 255) / 256 * 256;
+    if (in_pin + out_bytes <= kPinnedLimit) {  // result back through the pinned buffer, one synchronisation
+        void* pin = nullptr;
+        rc = net_stage_pinned(n, kPinnedLimit, &pin);
+        if (rc) return rc;
+        SZ_HIP(hipMemcpyAsync(static_cast<char*>(pin) + in_pin, dout, out_bytes, hipMemcpyDeviceToHost, nullptr));
+        SZ_HIP(hipStreamSynchronize(nullptr));
+        std::memcpy(out, static_cast<char*>(pin) + in_pin, out_bytes);
+    } else {
+        SZ_HIP(hipStreamSynchronize(nullptr));
+        SZ_HIP(hipMemcpy(out, dout, out_bytes, hipMemcpyDeviceToHost));
+    }
     return SZH_OK;
 }
 
@@ -123,19 +153,18 @@ int train_batch_host(Net* n, const float* x, uint64_t B, const float* target, fl
 {
     if (B == 0 || n->out == 0) return SZH_OK;  // lib.rs:1003-1005
     std::lock_guard<std::mutex> lock(n->mu);
-    DevBuf dx, dt;
-    int rc = dx.alloc(B * n->in * sizeof(float));
+    const size_t in_bytes = B * n->in * sizeof(float), t_bytes = n->out * sizeof(float);
+    void *dx = nullptr, *dt = nullptr;
+    int rc = stage_in(n, 0, x, in_bytes, 0, &dx);
     if (rc) return rc;
-    rc = dt.alloc(n->out * sizeof(float));
+    rc = stage_in(n, 2, target, t_bytes, (in_bytes + 255) / 256 * 256, &dt);
     if (rc) return rc;
-    SZ_HIP(hipMemcpy(dx.p, x, B * n->in * sizeof(float), hipMemcpyHostToDevice));
-    SZ_HIP(hipMemcpy(dt.p, target, n->out * sizeof(float), hipMemcpyHostToDevice));
     rc = net_zero_grad(n, nullptr);
     if (rc) return rc;
     AccumArgs a;
-    a.x_dev = dx.as<float>();
+    a.x_dev = static_cast<const float*>(dx);
     a.rows = B;
-    a.target_dev = dt.as<float>();
+    a.target_dev = static_cast<const float*>(dt);
     // train_batch takes the rows as given: every row counts, also an all-zero one
     rc = net_accumulate(n, a, nullptr);
     if (rc) return rc;
@@ -377,14 +406,14 @@ int vote_features_dev(Net* n, const float* d_feats, uint64_t n_win, float thresh
     if (capacity < n->out) { set_error("ids capacity %u < output size %u", capacity, n->out); return SZH_EINVAL; }
     std::vector<unsigned long long> counts(n->out, 0);
     if (n->out > 0 && n_win > 0) {
-        DevBuf d_cnt;
-        int rc = d_cnt.alloc(n->out * sizeof(unsigned long long));
+        void* d_cnt = nullptr;  // the net's staging buffer (the caller holds n->mu)
+        int rc = net_stage_dev(n, 3, n->out * sizeof(unsigned long long), &d_cnt);
         if (rc) return rc;
-        SZ_HIP(hipMemset(d_cnt.p, 0, n->out * sizeof(unsigned long long)));
-        rc = net_vote_dev(n, d_feats, n_win, threshold, d_cnt.as<unsigned long long>(), nullptr, nullptr);
+        SZ_HIP(hipMemsetAsync(d_cnt, 0, n->out * sizeof(unsigned long long), nullptr));
+        rc = net_vote_dev(n, d_feats, n_win, threshold, static_cast<unsigned long long*>(d_cnt), nullptr, nullptr);
         if (rc) return rc;
         SZ_HIP(hipStreamSynchronize(nullptr));
-        SZ_HIP(hipMemcpy(counts.data(), d_cnt.p, n->out * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        SZ_HIP(hipMemcpy(counts.data(), d_cnt, n->out * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     }
     *n_ids = order_votes(counts, ids);
     if (counts_out)

@@ -89,6 +89,16 @@ struct Workspace {
     uint64_t sl_w1 = 0, sl_w2 = 0, sl_w3 = 0, sl_b2 = 0, sl_b3 = 0;
 };
 
+// Grow-only device (and pinned host) buffers a net keeps for its host-memory entry points, so that a
+// per-window call (forward of one row, train_batch of eight) allocates nothing after the first.
+struct Staging {
+    static constexpr int kSlots = 4;
+    void* dev[kSlots] = {};
+    size_t dev_cap[kSlots] = {};
+    void* pinned = nullptr;
+    size_t pinned_cap = 0;
+};
+
 struct Net {
     uint32_t in = 0, h1 = 0, h2 = 0, out = 0;
     float* d_params = nullptr;  // [w1|b1|w2|b2|w3|b3]
@@ -96,6 +106,7 @@ struct Net {
     double* d_stats = nullptr;  // {loss, live rows} since zero_grad, then the same as running totals
     std::mutex mu;              // serialises host-API calls that share the workspace
     Workspace ws;
+    Staging stage;              // guarded by mu
     int device = 0;
     // metadata carried by model.npz (lib.rs:755-761)
     std::vector<std::vector<std::string>> file_lists;
@@ -163,6 +174,10 @@ int net_vote_dev(Net* n, const float* x_dev, uint64_t rows, float threshold, uns
 int net_pool_host(Net* n, const float* x_dev, uint64_t rows, int mode, float* out);
 // sizes the workspace for calls of up to `rows` rows, so that later calls allocate nothing
 int net_reserve_rows(Net* n, uint64_t rows);
+// device buffer `slot` of at least `bytes` (grow-only, owned by the net; call with n->mu held)
+int net_stage_dev(Net* n, int slot, size_t bytes, void** out);
+// pinned host buffer of at least `bytes` (grow-only; small transfers go through it without a pageable-copy stall)
+int net_stage_pinned(Net* n, size_t bytes, void** out);
 // identify_speaker_list's vote counts for a long recording, tile by tile (stream.cpp).  pcm is a
 // host or a device pointer; counts_dev[out] / psums_dev[out] (either may be null) are added to.
 int identify_tiled(Net* n, Extractor* e, const int16_t* pcm, bool pcm_on_device, uint64_t n_samples, float threshold,

@@ -7,6 +7,7 @@
 // activation / derivative is fused into the epilogue.  Weight gradients are contractions over
 // the batch: they are split over the batch dimension into slabs and summed by a second
 // kernel, so the result does not depend on scheduling order.
+#include <algorithm>
 #include <cstdlib>
 #include <mutex>
 #include <new>
@@ -1387,6 +1388,8 @@ void net_destroy(Net* n)
     if (w.mask) (void)hipFree(w.mask);
     if (w.stat_slab) (void)hipFree(w.stat_slab);
     if (n->d_stats) (void)hipFree(n->d_stats);
+    for (void* p : n->stage.dev) if (p) (void)hipFree(p);
+    if (n->stage.pinned) (void)hipHostFree(n->stage.pinned);
     delete n;
 }
 
@@ -1791,6 +1794,32 @@ int net_pool_host(Net* n, const float* x_dev, uint64_t rows, int mode, float* ou
 }
 
 int net_reserve_rows(Net* n, uint64_t rows) { return ensure_workspace(n, rows); }
+
+int net_stage_dev(Net* n, int slot, size_t bytes, void** out)
+{
+    Staging& st = n->stage;
+    if (st.dev_cap[slot] < bytes) {
+        if (st.dev[slot]) { (void)hipFree(st.dev[slot]); st.dev[slot] = nullptr; st.dev_cap[slot] = 0; }
+        const size_t cap = (std::max<size_t>(bytes, 4096) + 4095) / 4096 * 4096;
+        SZ_HIP(hipMalloc(&st.dev[slot], cap));
+        st.dev_cap[slot] = cap;
+    }
+    *out = st.dev[slot];
+    return SZH_OK;
+}
+
+int net_stage_pinned(Net* n, size_t bytes, void** out)
+{
+    Staging& st = n->stage;
+    if (st.pinned_cap < bytes) {
+        if (st.pinned) { (void)hipHostFree(st.pinned); st.pinned = nullptr; st.pinned_cap = 0; }
+        const size_t cap = (std::max<size_t>(bytes, 65536) + 4095) / 4096 * 4096;
+        SZ_HIP(hipHostMalloc(&st.pinned, cap, hipHostMallocDefault));
+        st.pinned_cap = cap;
+    }
+    *out = st.pinned;
+    return SZH_OK;
+}
 
 int net_vote_dev(Net* n, const float* x_dev, uint64_t rows, float threshold, unsigned long long* counts_dev,
                  double* psums_dev, hipStream_t s)

@@ -128,7 +128,14 @@ int identify_tiled(Net* n, Extractor* e, const int16_t* pcm, bool pcm_on_device,
             } else {
                 rc = capture_tile(r, 0, n, pcm, (uint32_t)B, tally, B * kHop);
                 if (rc) return rc;
-                for (uint64_t t = 0; t < n_mid; ++t) SZ_HIP(hipGraphLaunch(r.exec[0], r.compute));
+                for (uint64_t t = 0; t < n_mid; ++t) {
+                    SZ_HIP(hipGraphLaunch(r.exec[0], r.compute));
+                    // Bound the replays in flight.  Thousands of queued replays (4 843 for 100 h) exhaust
+                    // driver-side state that other processes need: while they were queued, and for as
+                    // long as this process lived afterwards, any newly started process on the GPU
+                    // crashed in its first kernel launch.
+                    if ((t & 255) == 255) SZ_HIP(hipStreamSynchronize(r.compute));
+                }
             }
         }
         rc = plan_create_tile(e, (last_first - 2) * kHop, 2, (uint32_t)last_rows, 0, &r.last);
@@ -183,6 +190,7 @@ int identify_tiled(Net* n, Extractor* e, const int16_t* pcm, bool pcm_on_device,
             SZ_HIP(hipGraphLaunch(r.exec[slot], r.compute));
         }
         SZ_HIP(hipEventRecord(r.done[slot], r.compute));
+        if ((j & 255) == 255) SZ_HIP(hipStreamSynchronize(r.compute));  // bounded queue depth, as above
     }
     SZ_HIP(hipStreamSynchronize(r.compute));
     return SZH_OK;

@@ -146,6 +146,8 @@ def test_100h_stream_by_periodicity(sz, nets):
     # every window is counted exactly once when the threshold lets all of them vote
     _, everyone = sz.identify_speaker_list_dev(net, stream.data_ptr(), n_samples, 0.0, ext, tile_windows=8192)
     assert int(everyone.sum()) == nw
+    del stream, block
+    torch.cuda.empty_cache()  # 64 GB of recording go back to the driver, not to the caching allocator
 
 
 @pytest.mark.parametrize("classes", [16, 40, 70, 1])

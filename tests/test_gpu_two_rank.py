@@ -92,7 +92,7 @@ def test_two_rank_processes_on_one_gpu(tmp_path):
     import two_rank_child as tr
 
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE="2")
-    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "two_rank_child.py"), str(tmp_path)],
+    procs = [subprocess.Popen([sys.executable, "-X", "faulthandler", os.path.join(ROOT, "tests", "two_rank_child.py"), str(tmp_path)],
                               env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE,
                               stderr=subprocess.STDOUT, text=True) for r in range(2)]
     outs = [p.communicate(timeout=300)[0] for p in procs]
