@@ -195,6 +195,9 @@ def main():
     ap.add_argument("--hidden2", type=int, default=256)
     ap.add_argument("--lr", type=float, default=0.01)
     ap.add_argument("--dropout", type=float, default=0.2)
+    ap.add_argument("--gemm", choices=["f32", "bf16x3"], default="f32",
+                    help="arithmetic of the three large products: f32 matrix instructions, or f32 operands split "
+                         "exactly into three bf16 pieces on the bf16 matrix cores (f32 accumulate)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal of the N > 1 path on fewer GPUs than ranks: "
@@ -238,6 +241,7 @@ def main():
     clip_speaker = (np.arange(args.clips) + rank * args.clips) % args.speakers
     labels = torch.from_numpy(np.repeat(clip_speaker, per_file).astype(np.int32)).to(dev)
     net = sz.SimpleNeuralNet(60, args.hidden1, args.hidden2, args.speakers, seed=42)  # same init on every rank
+    net.set_gemm(args.gemm)
     grad = torch.as_tensor(_DevView(net.grad_ptr(), net.grad_len()), device=dev)
     if comm is not None:
         comm.broadcast_params(net, 0, torch.cuda.current_stream().cuda_stream)

@@ -260,6 +260,18 @@ int szh_net_accumulate_dev(szh_net *net, const float *feats_dev, const int32_t *
  * tail (so after an all-reduce it is the global count).  No-op when live_rows == 0. */
 int szh_net_apply_grad_dev(szh_net *net, float lr, void *stream);
 int szh_net_forward_dev(szh_net *net, const float *feats_dev, uint64_t n, float *probs_dev, void *stream);
+/* Arithmetic of the large batched products (hidden1 x hidden2 layer forward, its delta and its
+ * weight gradient; the contractions of lib.rs:882-886 and 1034-1044 over a batch of windows).
+ * SZH_GEMM_F32: f32 operands on v_mfma_f32_32x32x2_f32 (the default).  SZH_GEMM_BF16X3: every f32
+ * operand split exactly into three bf16 values, six bf16 matrix instructions per product term,
+ * f32 accumulation: the bf16 matrix-core path at f32 accuracy.  Used when hidden1 and hidden2
+ * are multiples of 256 and a call has at least 1024 rows, otherwise the f32 kernels run.
+ * A new net takes its mode from the environment variable STREAMZ_GEMM ("bf16x3" or "f32").
+ * No counterpart in the reference, whose arithmetic is scalar f32. */
+#define SZH_GEMM_F32 0
+#define SZH_GEMM_BF16X3 1
+int szh_net_set_gemm(szh_net *net, int mode);
+int szh_net_get_gemm(const szh_net *net);
 /* Votes of identify_speaker_list over device-resident feature rows: counts_dev[output]
  * (uint64) is incremented; the caller zeroes it and orders the result. */
 int szh_net_vote_dev(szh_net *net, const float *feats_dev, uint64_t n, float threshold,

@@ -79,6 +79,8 @@ _SIGS = {
                                              C.POINTER(C.c_uint32), C.c_void_p]),
     "szh_net_grad_len": (C.c_uint64, [C.c_void_p]),
     "szh_net_grad_dev": (C.c_void_p, [C.c_void_p]),
+    "szh_net_set_gemm": (C.c_int, [C.c_void_p, C.c_int]),
+    "szh_net_get_gemm": (C.c_int, [C.c_void_p]),
     "szh_net_zero_grad_dev": (C.c_int, [C.c_void_p, C.c_void_p]),
     "szh_net_accumulate_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_float, C.c_uint64,
                                          C.c_void_p]),
@@ -347,6 +349,13 @@ class SimpleNeuralNet:
 
     def grad_ptr(self):
         return int(lib().szh_net_grad_dev(self._h))
+
+    def set_gemm(self, mode):
+        """"f32" or "bf16x3": arithmetic of the large batched products (SZH_GEMM_*)"""
+        _check(lib().szh_net_set_gemm(self._h, {"f32": 0, "bf16x3": 1}[mode]))
+
+    def get_gemm(self):
+        return ("f32", "bf16x3")[lib().szh_net_get_gemm(self._h)]
 
     def zero_grad_dev(self, stream=0):
         _check(lib().szh_net_zero_grad_dev(self._h, C.c_void_p(stream)))

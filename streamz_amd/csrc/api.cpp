@@ -606,6 +606,7 @@ int szh_net_clone(const szh_net* net, szh_net** out)
     n->file_lists = s->file_lists;
     n->sample_rate = s->sample_rate;
     n->bits = s->bits;
+    n->gemm_mode = s->gemm_mode;
     n->emb_vectors = s->emb_vectors; n->emb_mean = s->emb_mean; n->emb_std = s->emb_std; n->emb_dim = s->emb_dim;
     n->w4_cols = s->w4_cols; n->b4 = s->b4;
     *out = reinterpret_cast<szh_net*>(n);
@@ -974,6 +975,15 @@ static int check_device(int handle_device)
 
 uint64_t szh_net_grad_len(const szh_net* net) { return net ? reinterpret_cast<const Net*>(net)->param_count() + 2 : 0; }
 float* szh_net_grad_dev(szh_net* net) { return net ? reinterpret_cast<Net*>(net)->d_grad : nullptr; }
+int szh_net_set_gemm(szh_net* net, int mode)
+{
+    if (!net || (mode != SZH_GEMM_F32 && mode != SZH_GEMM_BF16X3)) { set_error("unknown GEMM mode"); return SZH_EINVAL; }
+    Net* n = reinterpret_cast<Net*>(net);
+    std::lock_guard<std::mutex> lock(n->mu);
+    n->gemm_mode = mode;
+    return SZH_OK;
+}
+int szh_net_get_gemm(const szh_net* net) { return net ? reinterpret_cast<const Net*>(net)->gemm_mode : SZH_GEMM_F32; }
 int szh_net_zero_grad_dev(szh_net* net, void* stream)
 {
     if (!net) { set_error("null argument"); return SZH_EINVAL; }

@@ -1,0 +1,455 @@
+// f32 GEMM on the bf16 matrix cores: every f32 operand value is split exactly into three bf16
+// pieces (x = hi + mid + lo, 8 significand bits each, round-to-nearest), and a product a.b is the
+// sum of the six piece products whose weight is at least 2^-16 of the leading one
+//   hi.hi + hi.mid + mid.hi + mid.mid + hi.lo + lo.hi
+// each of which is exact in f32; the accumulation is f32 inside v_mfma_f32_32x32x16_bf16.  The
+// three dropped products are below 2^-24 of a.b, the rounding unit of an f32 product.  Six bf16
+// MFMAs do the work of eight v_mfma_f32_32x32x2_f32 at one sixteenth of their cost each.
+//
+// Block tile 128 x 128, four waves of 64 x 64, K tile 32.  Both operand tiles sit in LDS as three
+// bf16 planes [plane][row or column of the tile][k], k contiguous (row stride 40 bf16 = 80 bytes:
+// the 16-byte fragment reads of 16 consecutive rows cover all 64 banks once).  Splitting happens
+// once per element on the way into LDS; weights arrive pre-split from split_planes_kernel.  The
+// accumulator layout is that of the f32 kernel, so the epilogues are shared with it.
+#pragma once
+#include "gemm_kernel.h"
+
+namespace sz {
+namespace gemm {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));  // a plain vector: arrays of it stay in registers
+
+constexpr int X3_KT = 32;
+constexpr int X3_LD = X3_KT + 8;        // bf16 per LDS row
+constexpr int X3_PLANE = BM * X3_LD;    // bf16 per plane of one operand tile
+constexpr int X3_TILE = 3 * X3_PLANE;
+
+enum X3Src {
+    X3_ROWS_F32 = 0,   // f32 X[row][k]: the tile dimension runs over rows, k is contiguous
+    X3_KROWS_F32 = 1,  // f32 X[k][col]: the tile dimension is contiguous, k runs over rows
+    X3_ROWS_SPLIT = 2  // bf16 planes P[plane][row][k] made by split_planes_kernel
+};
+
+// two f32 values -> their three bf16 pieces, packed (first value in the low half)
+__device__ __forceinline__ void split2(float x0, float x1, uint32_t& hi, uint32_t& mid, uint32_t& lo)
+{
+    f32x2 v = {x0, x1};
+    const bf16x2 h = __builtin_convertvector(v, bf16x2);
+    hi = __builtin_bit_cast(uint32_t, h);
+    f32x2 r = {x0 - __uint_as_float(hi << 16), x1 - __uint_as_float(hi & 0xffff0000u)};
+    const bf16x2 m = __builtin_convertvector(r, bf16x2);
+    mid = __builtin_bit_cast(uint32_t, m);
+    f32x2 q = {r[0] - __uint_as_float(mid << 16), r[1] - __uint_as_float(mid & 0xffff0000u)};
+    const bf16x2 l = __builtin_convertvector(q, bf16x2);
+    lo = __builtin_bit_cast(uint32_t, l);
+}
+
+// dst[plane][i] = piece `plane` of src[i]; count is even and both arrays are 4-byte aligned
+__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ src, uint64_t count,
+                                                           uint32_t* __restrict__ dst, uint64_t plane_words)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (2 * i >= count) return;
+    const float2 v = *reinterpret_cast<const float2*>(src + 2 * i);
+    uint32_t h, m, l;
+    split2(v.x, v.y, h, m, l);
+    dst[i] = h;
+    dst[plane_words + i] = m;
+    dst[2 * plane_words + i] = l;
+}
+
+template <int SRC> struct X3Operand;
+
+template <> struct X3Operand<X3_ROWS_F32> {
+    float4 f[4];
+    // rows r0 .. r0+127 (clamped to r_max - 1: what such rows produce is never stored), k0 .. k0+31
+    __device__ __forceinline__ void load(const void* base, int ld, uint64_t, int r0, int r_max, int k0, int)
+    {
+        const float* b = (const float*)base;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = threadIdx.x + 256 * i;
+            const int row = min(r0 + idx / 8, r_max - 1);
+            f[i] = *reinterpret_cast<const float4*>(b + (size_t)row * ld + k0 + 4 * (idx % 8));
+        }
+    }
+    __device__ __forceinline__ void stash(__bf16* S) const
+    {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = threadIdx.x + 256 * i;
+            uint2 h, m, l;
+            split2(f[i].x, f[i].y, h.x, m.x, l.x);
+            split2(f[i].z, f[i].w, h.y, m.y, l.y);
+            __bf16* at = S + (idx / 8) * X3_LD + 4 * (idx % 8);
+            *reinterpret_cast<uint2*>(at) = h;
+            *reinterpret_cast<uint2*>(at + X3_PLANE) = m;
+            *reinterpret_cast<uint2*>(at + 2 * X3_PLANE) = l;
+        }
+    }
+};
+
+template <> struct X3Operand<X3_KROWS_F32> {
+    float f[16];
+    // columns c0 .. c0+127 (all exist), k rows k0 .. k0+31, zero from k_end on
+    __device__ __forceinline__ void load(const void* base, int ld, uint64_t, int c0, int, int k0, int k_end)
+    {
+        const float* b = (const float*)base + (size_t)(k0 + 16 * (threadIdx.x >> 7)) * ld + c0 + (threadIdx.x & 127);
+        if (k0 + X3_KT <= k_end) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) f[i] = b[(size_t)i * ld];
+        } else {
+            const int left = k_end - k0 - 16 * (int)(threadIdx.x >> 7);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) f[i] = i < left ? b[(size_t)i * ld] : 0.0f;
+        }
+    }
+    __device__ __forceinline__ void stash(__bf16* S) const
+    {
+        uint32_t h[8], m[8], l[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) split2(f[2 * i], f[2 * i + 1], h[i], m[i], l[i]);
+        __bf16* at = S + (threadIdx.x & 127) * X3_LD + 16 * (threadIdx.x >> 7);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            *reinterpret_cast<uint4*>(at + 8 * q) = make_uint4(h[4 * q], h[4 * q + 1], h[4 * q + 2], h[4 * q + 3]);
+            *reinterpret_cast<uint4*>(at + X3_PLANE + 8 * q) = make_uint4(m[4 * q], m[4 * q + 1], m[4 * q + 2], m[4 * q + 3]);
+            *reinterpret_cast<uint4*>(at + 2 * X3_PLANE + 8 * q) = make_uint4(l[4 * q], l[4 * q + 1], l[4 * q + 2], l[4 * q + 3]);
+        }
+    }
+};
+
+template <> struct X3Operand<X3_ROWS_SPLIT> {
+    u32x4 f[6];
+    // planes of `plane` bf16 each, rows r0 .. r0+127 (all exist) of ld values, k0 .. k0+31
+    __device__ __forceinline__ void load(const void* base, int ld, uint64_t plane, int r0, int, int k0, int)
+    {
+        const __bf16* b = (const __bf16*)base;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int c = threadIdx.x + 256 * i;
+            f[i] = *reinterpret_cast<const u32x4*>(b + (size_t)(c >> 9) * plane + (size_t)(r0 + ((c & 511) >> 2)) * ld + k0 + 8 * (c & 3));
+        }
+    }
+    __device__ __forceinline__ void stash(__bf16* S) const
+    {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int c = threadIdx.x + 256 * i;
+            *reinterpret_cast<u32x4*>(S + (c >> 9) * X3_PLANE + ((c & 511) >> 2) * X3_LD + 8 * (c & 3)) = f[i];
+        }
+    }
+};
+
+// C[M][N] = epilogue(A . B) with the operands described by ASRC / BSRC:
+//   X3_ROWS_F32    A = g.A [M][K] (lda)            B = g.B [N][K] (ldb)
+//   X3_KROWS_F32   A = g.A [K][M] (lda)            B = g.B [K][N] (ldb)
+//   X3_ROWS_SPLIT                                   B = g.B planes [3][N][K] (ldb = K, g.b_plane apart)
+// Requirements checked by the host: the tile dimension of a KROWS or SPLIT operand is a multiple
+// of 128, K is a multiple of 32 unless both operands are KROWS (then k_chunk is), 16-byte aligned
+// rows for ROWS operands.
+template <int ASRC, int BSRC, int EPI, int TAG>
+__global__ __launch_bounds__(kGemmThreads) void gemm_x3_kernel(GemmArgs g)
+{
+    constexpr int TN = 2, WN = 64;
+    constexpr int DBG = TAG / 100;  // tuning harness only: 1 no MFMA, 2 no reloads, 4 no epilogue, 8 no stash
+    __shared__ __attribute__((aligned(16))) __bf16 As[X3_TILE];
+    __shared__ __attribute__((aligned(16))) __bf16 Bs[X3_TILE];
+    int bx, by, bz;
+    xcd_tile(bx, by, bz);
+    const int m0 = by * BM, n0 = bx * BN;
+    const int k_begin = bz * g.k_chunk;
+    const int k_end = min(g.K, k_begin + g.k_chunk);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, half = lane >> 5;
+
+    float* C = g.C;
+    if (EPI == EPI_SLAB) C += (size_t)bz * (size_t)g.M * (size_t)g.ldc;
+    f32x16 acc[2][TN];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    if (EPI == EPI_SLAB && g.slab_add) {
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                const int col = n0 + wn * WN + tn * 32 + l31;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    acc[tm][tn][r] = C[(size_t)row * g.ldc + col];
+                }
+            }
+    }
+
+    X3Operand<ASRC> fa;
+    X3Operand<BSRC> fb;
+    if (k_begin < k_end) {
+        fa.load(g.A, g.lda, 0, m0, g.M, k_begin, k_end);
+        fb.load(g.B, g.ldb, g.b_plane, n0, g.N, k_begin, k_end);
+    }
+    const __bf16* ar = As + (wm * 64 + l31) * X3_LD + 8 * half;
+    const __bf16* br = Bs + (wn * 64 + l31) * X3_LD + 8 * half;
+    for (int k0 = k_begin; k0 < k_end; k0 += X3_KT) {
+        __syncthreads();
+        if (!(DBG & 8) || k0 == k_begin) {
+            fa.stash(As);
+            fb.stash(Bs);
+        }
+        __syncthreads();
+        if (k0 + X3_KT < k_end && !(DBG & 2)) {
+            fa.load(g.A, g.lda, 0, m0, g.M, k0 + X3_KT, k_end);
+            fb.load(g.B, g.ldb, g.b_plane, n0, g.N, k0 + X3_KT, k_end);
+        }
+        if (DBG & 1) continue;
+#pragma unroll
+        for (int ks = 0; ks < X3_KT / 16; ++ks) {
+            bf16x8 a[2][3], b[TN][3];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    a[t][p] = *reinterpret_cast<const bf16x8*>(ar + p * X3_PLANE + t * 32 * X3_LD + 16 * ks);
+                    b[t][p] = *reinterpret_cast<const bf16x8*>(br + p * X3_PLANE + t * 32 * X3_LD + 16 * ks);
+                }
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) {
+                    f32x16 c = acc[tm][tn];
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][2], b[tn][0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][0], b[tn][2], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][1], b[tn][1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][1], b[tn][0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][0], b[tn][1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][0], b[tn][0], c, 0, 0, 0);
+                    acc[tm][tn] = c;
+                }
+        }
+    }
+    if (DBG & 4) {
+        if (acc[0][0][0] + acc[1][1][5] + acc[0][1][3] + acc[1][0][9] == 12345.678f) C[threadIdx.x] = 1.0f;
+        return;
+    }
+    finish_tile<EPI, BM, TN, WN>(g, C, acc, m0, n0, wm, wn, l31, half);
+}
+
+
+// ---- 256 x 256 block tile ------------------------------------------------------------------
+// Eight waves (4 x 2, each 64 rows x 128 columns = 2 x 4 MFMA tiles), one workgroup per compute
+// unit.  Operands are fetched 32 k at a time into registers and enter LDS 16 k at a time: LDS holds
+// two stages of [plane][256][16 k] per operand (row stride 24 bf16 = 48 bytes, conflict-free for the
+// 16-byte fragment reads), so one barrier per 16-k step suffices: while the MFMAs of step j read
+// stage j % 2, the other stage receives the k values of step j + 1, and once both halves of a
+// register tile are in LDS the next 32 k are requested, two steps ahead of their use.
+constexpr int XW_TM = 256, XW_TN = 256, XW_THREADS = 512;
+constexpr int XW_LD = 24;                    // bf16 per LDS row
+constexpr int XW_PLANE = 256 * XW_LD;        // bf16 per plane
+constexpr int XW_OPER = 3 * XW_PLANE;        // one operand, one stage
+constexpr int XW_STAGE = 2 * XW_OPER;        // A then B
+constexpr size_t XW_LDS_BYTES = 2 * XW_STAGE * sizeof(__bf16);
+
+template <int SRC> struct XWOperand;
+
+template <> struct XWOperand<X3_ROWS_F32> {
+    float4 f[4];  // f[2 j + h]: rows t / 4 + 128 j, k values 16 h + 4 (t % 4) ...
+    __device__ __forceinline__ void load(const void* base, int ld, uint64_t, int r0, int r_max, int k0, int)
+    {
+        const float* b = (const float*)base + k0 + 4 * (threadIdx.x & 3);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int row = min(r0 + (int)(threadIdx.x >> 2) + 128 * j, r_max - 1);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) f[2 * j + h] = *reinterpret_cast<const float4*>(b + (size_t)row * ld + 16 * h);
+        }
+    }
+    template <int H> __device__ __forceinline__ void stash(__bf16* S) const
+    {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            uint2 h, m, l;
+            split2(f[2 * j + H].x, f[2 * j + H].y, h.x, m.x, l.x);
+            split2(f[2 * j + H].z, f[2 * j + H].w, h.y, m.y, l.y);
+            __bf16* at = S + ((threadIdx.x >> 2) + 128 * j) * XW_LD + 4 * (threadIdx.x & 3);
+            *reinterpret_cast<uint2*>(at) = h;
+            *reinterpret_cast<uint2*>(at + XW_PLANE) = m;
+            *reinterpret_cast<uint2*>(at + 2 * XW_PLANE) = l;
+        }
+    }
+};
+
+template <> struct XWOperand<X3_KROWS_F32> {
+    float f[16];  // f[8 h + j]: column t % 256, k = 16 h + 8 (t / 256) + j
+    __device__ __forceinline__ void load(const void* base, int ld, uint64_t, int c0, int, int k0, int k_end)
+    {
+        const int kb = k0 + 8 * (int)(threadIdx.x >> 8);
+        const float* b = (const float*)base + (size_t)kb * ld + c0 + (threadIdx.x & 255);
+        if (k0 + 32 <= k_end) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) f[i] = b[(size_t)(16 * (i >> 3) + (i & 7)) * ld];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int k = 16 * (i >> 3) + (i & 7);
+                f[i] = kb + k < k_end ? b[(size_t)k * ld] : 0.0f;
+            }
+        }
+    }
+    template <int H> __device__ __forceinline__ void stash(__bf16* S) const
+    {
+        uint32_t h[4], m[4], l[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) split2(f[8 * H + 2 * i], f[8 * H + 2 * i + 1], h[i], m[i], l[i]);
+        __bf16* at = S + (threadIdx.x & 255) * XW_LD + 8 * (threadIdx.x >> 8);
+        *reinterpret_cast<uint4*>(at) = make_uint4(h[0], h[1], h[2], h[3]);
+        *reinterpret_cast<uint4*>(at + XW_PLANE) = make_uint4(m[0], m[1], m[2], m[3]);
+        *reinterpret_cast<uint4*>(at + 2 * XW_PLANE) = make_uint4(l[0], l[1], l[2], l[3]);
+    }
+};
+
+template <> struct XWOperand<X3_ROWS_SPLIT> {
+    u32x4 f[6];  // f[2 p + h]: plane p, row t / 2, k values 16 h + 8 (t % 2) ...
+    __device__ __forceinline__ void load(const void* base, int ld, uint64_t plane, int r0, int, int k0, int)
+    {
+        const __bf16* b = (const __bf16*)base + (size_t)(r0 + (threadIdx.x >> 1)) * ld + k0 + 8 * (threadIdx.x & 1);
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) f[2 * p + h] = *reinterpret_cast<const u32x4*>(b + (size_t)p * plane + 16 * h);
+    }
+    template <int H> __device__ __forceinline__ void stash(__bf16* S) const
+    {
+        __bf16* at = S + (threadIdx.x >> 1) * XW_LD + 8 * (threadIdx.x & 1);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4*>(at + p * XW_PLANE) = f[2 * p + H];
+    }
+};
+
+// Same operands and epilogues as gemm_x3_kernel.  Requirements checked by the host: N and, for a
+// KROWS A, M are multiples of 256; the K range of every grid z index is a multiple of 32 long
+// (rows past K read as zero for KROWS operands); g.lda / g.ldb rows 16-byte aligned.
+template <int ASRC, int BSRC, int EPI, int TAG>
+__global__ __launch_bounds__(XW_THREADS) void gemm_x3w_kernel(GemmArgs g)
+{
+    constexpr int TN = 4, WN = 128;
+    constexpr int DBG = TAG / 100;  // tuning harness only: 1 no MFMA, 2 no reloads, 4 no epilogue, 8 no stash
+    extern __shared__ __attribute__((aligned(16))) unsigned char xw_lds[];
+    __bf16* L = reinterpret_cast<__bf16*>(xw_lds);
+    int bx, by, bz;
+    xcd_tile(bx, by, bz);
+    const int m0 = by * XW_TM, n0 = bx * XW_TN;
+    const int k_begin = bz * g.k_chunk;
+    const int k_end = min(g.K, k_begin + g.k_chunk);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, half = lane >> 5;
+
+    float* C = g.C;
+    if (EPI == EPI_SLAB) C += (size_t)bz * (size_t)g.M * (size_t)g.ldc;
+    f32x16 acc[2][TN];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    if (EPI == EPI_SLAB && g.slab_add) {
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                const int col = n0 + wn * WN + tn * 32 + l31;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    acc[tm][tn][r] = C[(size_t)row * g.ldc + col];
+                }
+            }
+    }
+    if (k_begin >= k_end) {
+        finish_tile<EPI, XW_TM, TN, WN>(g, C, acc, m0, n0, wm, wn, l31, half);
+        return;
+    }
+
+    XWOperand<ASRC> fa;
+    XWOperand<BSRC> fb;
+    fa.load(g.A, g.lda, 0, m0, g.M, k_begin, k_end);
+    fb.load(g.B, g.ldb, g.b_plane, n0, g.N, k_begin, k_end);
+    fa.template stash<0>(L);
+    fb.template stash<0>(L + XW_OPER);
+    __syncthreads();
+    const int a_off = (wm * 64 + l31) * XW_LD + 8 * half;
+    const int b_off = XW_OPER + (wn * WN + l31) * XW_LD + 8 * half;
+    bf16x8 a[2][3];
+    auto load_a = [&](const __bf16* S) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) a[t][p] = *reinterpret_cast<const bf16x8*>(S + a_off + p * XW_PLANE + t * 32 * XW_LD);
+    };
+    auto multiply = [&](const __bf16* S, int tn0) {  // column tiles tn0, tn0 + 1
+        if (DBG & 1) return;
+#pragma unroll
+        for (int tn = tn0; tn < tn0 + 2; ++tn) {
+            bf16x8 b[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) b[p] = *reinterpret_cast<const bf16x8*>(S + b_off + p * XW_PLANE + tn * 32 * XW_LD);
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm) {
+                f32x16 c = acc[tm][tn];
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][2], b[0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][0], b[2], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][1], b[1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][1], b[0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][0], b[1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][0], b[0], c, 0, 0, 0);
+                acc[tm][tn] = c;
+            }
+        }
+    };
+    // two 16-k steps per trip: the registers hold the 32 k starting at k0
+    for (int k0 = k_begin; k0 < k_end; k0 += 32) {
+        // step 0 reads stage 0; stage 1 receives the second half of the register tile, after
+        // which the registers are free for the next 32 k
+        const bool more = k0 + 32 < k_end;
+        load_a(L);
+        if (!(DBG & 8)) {
+            fa.template stash<1>(L + XW_STAGE);
+            fb.template stash<1>(L + XW_STAGE + XW_OPER);
+        }
+        if (more && !(DBG & 2)) {
+            fa.load(g.A, g.lda, 0, m0, g.M, k0 + 32, k_end);
+            fb.load(g.B, g.ldb, g.b_plane, n0, g.N, k0 + 32, k_end);
+        }
+        multiply(L, 0);
+        multiply(L, 2);
+        __syncthreads();
+        // step 1 reads stage 1; stage 0 receives the first half of the next register tile, as
+        // late as possible: its loads were issued one step ago
+        load_a(L + XW_STAGE);
+        multiply(L + XW_STAGE, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more && !(DBG & 8)) {
+            fa.template stash<0>(L);
+            fb.template stash<0>(L + XW_OPER);
+        }
+        multiply(L + XW_STAGE, 2);
+        __syncthreads();
+    }
+    if (DBG & 4) {
+        if (acc[0][0][0] + acc[1][1][5] + acc[0][3][3] + acc[1][2][9] == 12345.678f) C[threadIdx.x] = 1.0f;
+        return;
+    }
+    finish_tile<EPI, XW_TM, TN, WN>(g, C, acc, m0, n0, wm, wn, l31, half);
+}
+
+}  // namespace gemm
+}  // namespace sz

@@ -54,6 +54,7 @@ struct GemmArgs {
                         // so edge tiles of A may be fetched without bounds checks
     uint32_t* mask = nullptr;  // EPI_*_MASK: [ceil(M / 32)][N] sign bits of the ReLU layer, one word per
                                // column and block of 32 rows (what one lane of an MFMA tile holds)
+    uint64_t b_plane = 0;      // split-bf16 kernel: elements between the three planes of a pre-split B
 };
 
 struct Frag4 { float v[4]; };
@@ -174,6 +175,98 @@ __device__ __forceinline__ void fetch_krows_fast(const float* base, int ld, int 
     }
 }
 
+// Workgroups are handed to the 8 XCDs round-robin in launch order.  Tiles are renumbered so
+// that each XCD works on one contiguous run of them (column tiles of a row tile, then row
+// tiles, then K ranges): neighbours that share operand rows then share one L2.
+__device__ __forceinline__ void xcd_tile(int& bx, int& by, int& bz)
+{
+    const unsigned nb = gridDim.x * gridDim.y * gridDim.z;
+    const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const unsigned xcd = lin & 7u, slot = lin >> 3, q = nb >> 3, r = nb & 7u;
+    const unsigned t = xcd < r ? xcd * (q + 1) + slot : r * (q + 1) + (xcd - r) * q + slot;
+    bx = (int)(t % gridDim.x);
+    by = (int)((t / gridDim.x) % gridDim.y);
+    bz = (int)(t / (gridDim.x * gridDim.y));
+}
+
+// Epilogue shared by the kernels whose accumulators have the 32x32 MFMA layout: a lane holds
+// column `col` of a tile and the 16 rows (r & 3) + 8 (r >> 2) + 4 half.
+template <int EPI, int TM, int TN, int WN>
+__device__ __forceinline__ void finish_tile(const GemmArgs& g, float* C, f32x16 (&acc)[2][TN], int m0, int n0, int wm, int wn,
+                                            int l31, int half)
+{
+    // One MFMA tile is 32 rows x 32 columns; a lane holds column `col` and the 16 rows
+    // (r & 3) + 8 (r >> 2) + 4 half.  Its 16 sign bits and those of lane ^ 32 make the mask word
+    // of (row block, col).  Everything the epilogue reads is requested before the first store
+    // (the memory counter of this ISA covers loads and stores alike).
+    float biasv[TN];
+    uint32_t mwordv[2][TN];
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int colc = min(n0 + wn * WN + tn * 32 + l31, g.N - 1);
+        biasv[tn] = 0.0f;
+        if (EPI == EPI_BIAS_RELU || EPI == EPI_BIAS_TANH || EPI == EPI_BIAS || EPI == EPI_BIAS_RELU_MASK)
+            biasv[tn] = g.bias[colc];
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm) {
+            mwordv[tm][tn] = 0;
+            if (EPI == EPI_MUL_MASK) mwordv[tm][tn] = g.mask[(size_t)((m0 + wm * 64 + tm * 32) >> 5) * g.N + colc];
+        }
+    }
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            const int col = n0 + wn * WN + tn * 32 + l31;
+            if (col >= g.N) continue;
+            const float bias = biasv[tn];
+            const size_t mask_at = (size_t)((m0 + wm * 64 + tm * 32) >> 5) * g.N + col;
+            uint32_t mword = mwordv[tm][tn];
+            if (EPI == EPI_BIAS_RELU_MASK) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (acc[tm][tn][r] + bias > 0.0f) mword |= 1u << ((r & 3) + 8 * (r >> 2) + 4 * half);
+                mword |= (uint32_t)__shfl_xor((int)mword, 32);
+                if (half == 0) g.mask[mask_at] = mword;
+            }
+            const int row_base = m0 + wm * 64 + tm * 32 + 4 * half;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rofs = (r & 3) + 8 * (r >> 2);
+                const int row = min(row_base + rofs, g.M - 1);  // clamped: only used to read aux
+                float v = acc[tm][tn][r];
+                if (EPI == EPI_BIAS_RELU_MASK || EPI == EPI_BIAS_RELU) { v += bias; v = v > 0.0f ? v : 0.0f; }
+                else if (EPI == EPI_BIAS_TANH) v = fast_tanh(v + bias);
+                else if (EPI == EPI_BIAS) v += bias;
+                else if (EPI == EPI_MUL_DTANH) { const float h = g.aux[(size_t)row * g.ldaux + col]; v *= (1.0f - h * h); }
+                else if (EPI == EPI_MUL_DRELU) { const float h = g.aux[(size_t)row * g.ldaux + col]; v *= (h > 0.0f ? 1.0f : 0.0f); }
+                else if (EPI == EPI_MUL_MASK) { if (!((mword >> (rofs + 4 * half)) & 1u)) v = 0.0f; }
+                acc[tm][tn][r] = v;
+            }
+        }
+    // Second pass: the stores.  Every value was finished above, in place, so everything the
+    // epilogue loads has arrived before the first store and the stores go out back to back.
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            const int col = n0 + wn * WN + tn * 32 + l31;
+            if (col >= g.N) continue;
+            const int row_base = m0 + wm * 64 + tm * 32 + 4 * half;
+            float* cp = C + (size_t)row_base * g.ldc + col;
+            if (m0 + TM <= g.M) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) cp[(size_t)((r & 3) + 8 * (r >> 2)) * g.ldc] = acc[tm][tn][r];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rofs = (r & 3) + 8 * (r >> 2);
+                    if (row_base + rofs < g.M) cp[(size_t)rofs * g.ldc] = acc[tm][tn][r];
+                }
+            }
+        }
+}
+
 // TAG only separates instantiations, so that each call site is its own kernel in a profile.
 // TM = rows of the block tile, KT = K tile (16 or 32), DB = double-buffered LDS tiles.
 template <int AM, int BMd, int EPI, int TAG, int TM, int KT, int DB>
@@ -189,19 +282,8 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_kernel(GemmArgs g)
     constexpr int A_TILE = AM == A_ROWS ? TM * LDA : BK * LDT;
     __shared__ __attribute__((aligned(16))) float As_[(DB ? 2 : 1) * A_TILE];
     __shared__ __attribute__((aligned(16))) float Bs_[(DB ? 2 : 1) * BK * LDT];
-    // Workgroups are handed to the 8 XCDs round-robin in launch order.  Tiles are renumbered so
-    // that each XCD works on one contiguous run of them (column tiles of a row tile, then row
-    // tiles, then K ranges): neighbours that share operand rows then share one L2.
     int bx, by, bz;
-    {
-        const unsigned nb = gridDim.x * gridDim.y * gridDim.z;
-        const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-        const unsigned xcd = lin & 7u, slot = lin >> 3, q = nb >> 3, r = nb & 7u;
-        const unsigned t = xcd < r ? xcd * (q + 1) + slot : r * (q + 1) + (xcd - r) * q + slot;
-        bx = (int)(t % gridDim.x);
-        by = (int)((t / gridDim.x) % gridDim.y);
-        bz = (int)(t / (gridDim.x * gridDim.y));
-    }
+    xcd_tile(bx, by, bz);
     const int m0 = by * TM, n0 = bx * BN;
     const int k_begin = bz * g.k_chunk;
     const int k_end = min(g.K, k_begin + g.k_chunk);
@@ -339,76 +421,7 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_kernel(GemmArgs g)
         }
     }
 
-    // One MFMA tile is 32 rows x 32 columns; a lane holds column `col` and the 16 rows
-    // (r & 3) + 8 (r >> 2) + 4 half.  Its 16 sign bits and those of lane ^ 32 make the mask word
-    // of (row block, col).  Everything the epilogue reads is requested before the first store
-    // (the memory counter of this ISA covers loads and stores alike).
-    float biasv[TN];
-    uint32_t mwordv[2][TN];
-#pragma unroll
-    for (int tn = 0; tn < TN; ++tn) {
-        const int colc = min(n0 + wn * WN + tn * 32 + l31, g.N - 1);
-        biasv[tn] = 0.0f;
-        if (EPI == EPI_BIAS_RELU || EPI == EPI_BIAS_TANH || EPI == EPI_BIAS || EPI == EPI_BIAS_RELU_MASK)
-            biasv[tn] = g.bias[colc];
-#pragma unroll
-        for (int tm = 0; tm < 2; ++tm) {
-            mwordv[tm][tn] = 0;
-            if (EPI == EPI_MUL_MASK) mwordv[tm][tn] = g.mask[(size_t)((m0 + wm * 64 + tm * 32) >> 5) * g.N + colc];
-        }
-    }
-#pragma unroll
-    for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn) {
-            const int col = n0 + wn * WN + tn * 32 + l31;
-            if (col >= g.N) continue;
-            const float bias = biasv[tn];
-            const size_t mask_at = (size_t)((m0 + wm * 64 + tm * 32) >> 5) * g.N + col;
-            uint32_t mword = mwordv[tm][tn];
-            if (EPI == EPI_BIAS_RELU_MASK) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (acc[tm][tn][r] + bias > 0.0f) mword |= 1u << ((r & 3) + 8 * (r >> 2) + 4 * half);
-                mword |= (uint32_t)__shfl_xor((int)mword, 32);
-                if (half == 0) g.mask[mask_at] = mword;
-            }
-            const int row_base = m0 + wm * 64 + tm * 32 + 4 * half;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int rofs = (r & 3) + 8 * (r >> 2);
-                const int row = min(row_base + rofs, g.M - 1);  // clamped: only used to read aux
-                float v = acc[tm][tn][r];
-                if (EPI == EPI_BIAS_RELU_MASK || EPI == EPI_BIAS_RELU) { v += bias; v = v > 0.0f ? v : 0.0f; }
-                else if (EPI == EPI_BIAS_TANH) v = fast_tanh(v + bias);
-                else if (EPI == EPI_BIAS) v += bias;
-                else if (EPI == EPI_MUL_DTANH) { const float h = g.aux[(size_t)row * g.ldaux + col]; v *= (1.0f - h * h); }
-                else if (EPI == EPI_MUL_DRELU) { const float h = g.aux[(size_t)row * g.ldaux + col]; v *= (h > 0.0f ? 1.0f : 0.0f); }
-                else if (EPI == EPI_MUL_MASK) { if (!((mword >> (rofs + 4 * half)) & 1u)) v = 0.0f; }
-                acc[tm][tn][r] = v;
-            }
-        }
-    // Second pass: the stores.  Every value was finished above, in place, so everything the
-    // epilogue loads has arrived before the first store and the stores go out back to back.
-#pragma unroll
-    for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn) {
-            const int col = n0 + wn * WN + tn * 32 + l31;
-            if (col >= g.N) continue;
-            const int row_base = m0 + wm * 64 + tm * 32 + 4 * half;
-            float* cp = C + (size_t)row_base * g.ldc + col;
-            if (m0 + TM <= g.M) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) cp[(size_t)((r & 3) + 8 * (r >> 2)) * g.ldc] = acc[tm][tn][r];
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int rofs = (r & 3) + 8 * (r >> 2);
-                    if (row_base + rofs < g.M) cp[(size_t)rofs * g.ldc] = acc[tm][tn][r];
-                }
-            }
-        }
+    finish_tile<EPI, TM, TN, WN>(g, C, acc, m0, n0, wm, wn, l31, half);
 }
 
 

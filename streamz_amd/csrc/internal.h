@@ -83,6 +83,7 @@ struct Workspace {
           *w2t = nullptr;
     uint8_t* live = nullptr;
     uint32_t* mask = nullptr;     // [rows / 32][hidden1] sign bits of the first layer
+    uint32_t* w2s = nullptr;      // bf16 planes of w2^T and of w2 (split-bf16 kernels), two bf16 per word
     double* stat_slab = nullptr;  // per-workgroup {loss, live rows} partials of the head kernels
     uint64_t slab_floats = 0;
     // regions of `slab` (float offsets): split-K partials of dW1|db1, dW2, dW3|db3 and db2
@@ -108,6 +109,7 @@ struct Net {
     Workspace ws;
     Staging stage;              // guarded by mu
     int device = 0;
+    int gemm_mode = 0;          // SZH_GEMM_*: arithmetic of the large batched products
     // metadata carried by model.npz (lib.rs:755-761)
     std::vector<std::vector<std::string>> file_lists;
     uint32_t sample_rate = 44100;

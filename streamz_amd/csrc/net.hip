@@ -12,6 +12,7 @@
 #include <mutex>
 #include <new>
 
+#include "gemm_bf16x3.h"
 #include "gemm_kernel.h"
 #include "internal.h"
 #include "prof.h"
@@ -50,6 +51,27 @@ int launch_gemm(GemmArgs g, int splits, hipStream_t s)
     }
     SZ_HIP(hipGetLastError());
     return SZH_OK;
+}
+
+// The three large products of a training chunk on the bf16 matrix cores with every f32 operand
+// split exactly into three bf16 pieces (gemm_bf16x3.h).
+template <int ASRC, int BSRC, int EPI, int TAG>
+int launch_gemm_x3(GemmArgs g, int splits, hipStream_t s)
+{
+    if (g.M <= 0 || g.N <= 0) return SZH_OK;
+    if (int rc = allow_dynamic_lds((const void*)gemm_x3w_kernel<ASRC, BSRC, EPI, TAG>, XW_LDS_BYTES)) return rc;
+    ProfScope prof(kGemmTagName[TAG], s);
+    dim3 grid((g.N + XW_TN - 1) / XW_TN, (g.M + XW_TM - 1) / XW_TM, splits);
+    hipLaunchKernelGGL((gemm_x3w_kernel<ASRC, BSRC, EPI, TAG>), grid, dim3(XW_THREADS), XW_LDS_BYTES, s, g);
+    SZ_HIP(hipGetLastError());
+    return SZH_OK;
+}
+
+// whether a call of `rows` rows takes the split-bf16 kernels: opted in, whole 256-wide tiles in both
+// hidden dimensions, and enough rows that 256-row tiles are not mostly padding
+inline bool use_x3(const Net* n, uint64_t rows)
+{
+    return n->gemm_mode == SZH_GEMM_BF16X3 && n->h1 % 256 == 0 && n->h2 % 256 == 0 && rows >= 1024;
 }
 
 // ---- row preparation: gather by permutation, input dropout, all-zero flag -------------
@@ -1223,6 +1245,12 @@ static uint64_t chunk_rows(const Net* n)
 // Most split-K slabs of a weight-gradient product: enough that tiles x splits is several
 // workgroups per CU (dW1 has only 4 column tiles, dW2 has 8 tiles)
 constexpr uint64_t kMaxSplits = 64, kMaxSplitsW1 = 256;
+// dW2 on 256 x 256 tiles has a quarter of the tiles: more K ranges keep every CU busy
+inline uint64_t w2_split_cap(const Net* n)
+{
+    const uint64_t tiles = (uint64_t)((n->h1 + 255) / 256) * ((n->h2 + 255) / 256);
+    return tiles <= 4 ? 2 * kMaxSplits : kMaxSplits;
+}
 
 int ensure_workspace(Net* n, uint64_t rows)
 {
@@ -1231,6 +1259,7 @@ int ensure_workspace(Net* n, uint64_t rows)
     if (w.rows >= rows && w.out == n->out) return SZH_OK;
     float** ptrs[] = {&w.xd, &w.h1, &w.h2, &w.p, &w.d2, &w.d1, &w.slab, &w.w2t};
     for (float** p : ptrs) { if (*p) (void)hipFree(*p); *p = nullptr; }
+    if (w.w2s) { (void)hipFree(w.w2s); w.w2s = nullptr; }
     if (w.live) { (void)hipFree(w.live); w.live = nullptr; }
     if (w.mask) { (void)hipFree(w.mask); w.mask = nullptr; }
     if (w.stat_slab) { (void)hipFree(w.stat_slab); w.stat_slab = nullptr; }
@@ -1241,7 +1270,7 @@ int ensure_workspace(Net* n, uint64_t rows)
     const uint64_t len3 = (uint64_t)(n->h2 + 1) * n->out;
     w.sl_w1 = 0;
     w.sl_w2 = w.sl_w1 + kMaxSplitsW1 * (uint64_t)(n->in + 1) * n->h1;
-    w.sl_w3 = w.sl_w2 + kMaxSplits * (uint64_t)n->h1 * n->h2;
+    w.sl_w3 = w.sl_w2 + w2_split_cap(n) * (uint64_t)n->h1 * n->h2;
     w.sl_b2 = w.sl_w3 + std::max<uint64_t>(kMaxSplits, head_blocks) * len3;
     w.sl_b3 = w.sl_b2 + std::max<uint64_t>(kMaxSplits, head_blocks) * n->h2;
     w.slab_floats = w.sl_b3 + head_blocks * 64;
@@ -1255,7 +1284,10 @@ int ensure_workspace(Net* n, uint64_t rows)
     SZ_HIP(hipMalloc((void**)&w.d1, R * n->h1 * sizeof(float)));
     SZ_HIP(hipMalloc((void**)&w.slab, w.slab_floats * sizeof(float)));
     SZ_HIP(hipMalloc((void**)&w.live, R));
-    SZ_HIP(hipMalloc((void**)&w.mask, ((R + 127) / 128 * 4) * (uint64_t)n->h1 * sizeof(uint32_t)));
+    // mask words up to the next 256-row tile boundary: the wide kernels read them for whole tiles
+    SZ_HIP(hipMalloc((void**)&w.mask, ((R + 255) / 256 * 8) * (uint64_t)n->h1 * sizeof(uint32_t)));
+    // w2 and its transpose as bf16 planes, [2][3][hidden1 * hidden2]
+    SZ_HIP(hipMalloc((void**)&w.w2s, 2 * 3 * ((uint64_t)n->h1 * n->h2 + 1) * sizeof(uint16_t)));
     SZ_HIP(hipMalloc((void**)&w.stat_slab, 2 * head_blocks * sizeof(double)));
     SZ_HIP(hipMalloc((void**)&w.w2t, ((uint64_t)n->h1 * n->h2 + 8 * 64 * 4 * ((n->h2 + 15) / 16)) * sizeof(float)));
     w.rows = R;
@@ -1263,9 +1295,31 @@ int ensure_workspace(Net* n, uint64_t rows)
     return SZH_OK;
 }
 
-// hidden layers of `rows` rows (rows <= workspace capacity): h1, h2 in the workspace
+// w2^T (and, for the backward pass, w2) as bf16 planes for the split-bf16 kernels; w.w2t must hold
+// the transposed weights when transposed_ready
+int prepare_w2_planes(Net* n, bool backward, bool transposed_ready, hipStream_t s)
+{
+    Workspace& w = n->ws;
+    const float* P = n->d_params;
+    const uint64_t count = (uint64_t)n->h1 * n->h2;
+    ProfScope prof("w2split", s);
+    if (!transposed_ready) {
+        hipLaunchKernelGGL(transpose_kernel, dim3((n->h2 + 31) / 32, (n->h1 + 31) / 32), dim3(256), 0, s,
+                           P + n->off_w2(), (int)n->h1, (int)n->h2, w.w2t);
+    }
+    const unsigned blocks = (unsigned)((count / 2 + 255) / 256);
+    hipLaunchKernelGGL(split_planes_kernel, dim3(blocks), dim3(256), 0, s, w.w2t, count, w.w2s, count / 2);
+    if (backward)
+        hipLaunchKernelGGL(split_planes_kernel, dim3(blocks), dim3(256), 0, s, P + n->off_w2(), count, w.w2s + 3 * (count / 2),
+                           count / 2);
+    SZ_HIP(hipGetLastError());
+    return SZH_OK;
+}
+
+// hidden layers of `rows` rows (rows <= workspace capacity): h1, h2 in the workspace.  With x3 the
+// second layer runs on the split-bf16 kernel and prepare_w2_planes has been called.
 int forward_hidden(Net* n, const float* x, uint64_t rows, bool relu2, hipStream_t s, uint32_t* relu_mask = nullptr,
-                   int ldx = 0)
+                   int ldx = 0, bool x3 = false)
 {
     Workspace& w = n->ws;
     const float* P = n->d_params;
@@ -1280,6 +1334,11 @@ int forward_hidden(Net* n, const float* x, uint64_t rows, bool relu2, hipStream_
     g = GemmArgs{};
     g.A = w.h1; g.lda = n->h1; g.B = P + n->off_w2(); g.ldb = n->h2; g.C = w.h2; g.ldc = n->h2;
     g.M = (int)rows; g.N = n->h2; g.K = n->h1; g.k_chunk = n->h1; g.bias = P + n->off_b2();
+    if (x3) {  // B as [hidden2][hidden1] planes
+        g.B = (const float*)w.w2s; g.ldb = n->h1; g.b_plane = (uint64_t)n->h1 * n->h2;
+        return relu2 ? launch_gemm_x3<X3_ROWS_F32, X3_ROWS_SPLIT, EPI_BIAS_RELU, T_FWD2>(g, 1, s)
+                     : launch_gemm_x3<X3_ROWS_F32, X3_ROWS_SPLIT, EPI_BIAS_TANH, T_FWD2>(g, 1, s);
+    }
     return relu2 ? launch_gemm<A_ROWS, B_KROWS, EPI_BIAS_RELU, T_FWD2>(g, 1, s)
                  : launch_gemm<A_ROWS, B_KROWS, EPI_BIAS_TANH, T_FWD2>(g, 1, s);
 }
@@ -1324,6 +1383,18 @@ int grad_gemm(const float* A, int lda, const float* B, int ldb, int M, int N, ui
     return launch_gemm<A_KROWS, B_KROWS, EPI_SLAB, TAG>(g, (int)((rows + sp.k_chunk - 1) / sp.k_chunk), s);
 }
 
+// the same contraction on the split-bf16 kernel (M and N multiples of 256, no bias row)
+template <int TAG>
+int grad_gemm_x3(const float* A, int lda, const float* B, int ldb, int M, int N, uint64_t rows, float* slab,
+                 const SplitPlan& sp, bool add, hipStream_t s)
+{
+    GemmArgs g{};
+    g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = slab; g.ldc = N;
+    g.M = M; g.N = N; g.K = (int)rows; g.k_chunk = sp.k_chunk;
+    g.slab_add = add ? 1 : 0;
+    return launch_gemm_x3<X3_KROWS_F32, X3_KROWS_F32, EPI_SLAB, TAG>(g, (int)((rows + sp.k_chunk - 1) / sp.k_chunk), s);
+}
+
 int reduce_slabs(const float* slab, int splits, uint64_t len, float* grad, hipStream_t s)
 {
     ProfScope prof("reduce", s);
@@ -1352,6 +1423,7 @@ int net_create(uint32_t in, uint32_t h1, uint32_t h2, uint32_t out, const float*
     Net* n = new (std::nothrow) Net();
     if (!n) { set_error("out of host memory"); return SZH_ENOMEM; }
     n->in = in; n->h1 = h1; n->h2 = h2; n->out = out;
+    if (const char* e = std::getenv("STREAMZ_GEMM")) n->gemm_mode = std::string(e) == "bf16x3" ? SZH_GEMM_BF16X3 : SZH_GEMM_F32;
     n->file_lists.resize(out);
     const uint64_t np = n->param_count();
     hipError_t he = hipGetDevice(&n->device);
@@ -1384,6 +1456,7 @@ void net_destroy(Net* n)
     Workspace& w = n->ws;
     float* ptrs[] = {w.xd, w.h1, w.h2, w.p, w.d2, w.d1, w.slab, w.w2t, n->d_params, n->d_grad};
     for (float* p : ptrs) if (p) (void)hipFree(p);
+    if (w.w2s) (void)hipFree(w.w2s);
     if (w.live) (void)hipFree(w.live);
     if (w.mask) (void)hipFree(w.mask);
     if (w.stat_slab) (void)hipFree(w.stat_slab);
@@ -1443,9 +1516,11 @@ int net_forward_dev(Net* n, const float* x_dev, uint64_t rows, float* out_dev, F
     int rc = ensure_workspace(n, rows);
     if (rc) return rc;
     const uint32_t ow = kind == kFwdProbs ? n->out : n->h2;
+    const bool x3 = use_x3(n, rows);
+    if (x3 && (rc = prepare_w2_planes(n, false, false, s))) return rc;
     for (uint64_t r0 = 0; r0 < rows; r0 += chunk_rows(n)) {
         const uint64_t R = std::min<uint64_t>(chunk_rows(n), rows - r0);
-        rc = forward_hidden(n, x_dev + r0 * n->in, R, kind == kFwdEmbedRelu, s);
+        rc = forward_hidden(n, x_dev + r0 * n->in, R, kind == kFwdEmbedRelu, s, nullptr, 0, x3);
         if (rc) return rc;
         float* o = out_dev + r0 * ow;
         if (kind == kFwdProbs) {
@@ -1528,6 +1603,8 @@ int net_accumulate(Net* n, const AccumArgs& a, hipStream_t s)
                            P + n->off_w2(), (int)n->h1, (int)n->h2, w.w2t);
     }
     SZ_HIP(hipGetLastError());
+    const bool x3 = use_x3(n, a.rows);
+    if (x3 && (rc = prepare_w2_planes(n, true, true, s))) return rc;
     float* w3tab = w.w2t + (uint64_t)n->h1 * n->h2;  // behind the transposed w2 (a multiple of 4 floats in)
     // Every chunk adds its split-K partials into the same slabs (the first one overwrites them);
     // the slabs are folded into the gradient vector once, after the last chunk.
@@ -1538,6 +1615,7 @@ int net_accumulate(Net* n, const AccumArgs& a, hipStream_t s)
     const uint64_t rows0 = std::min<uint64_t>(chunk, a.rows);
     const SplitPlan sp = plan_splits(rows0, (int)kMaxSplits);
     const SplitPlan sp1 = plan_splits(rows0, (int)kMaxSplitsW1);
+    const SplitPlan sp2 = x3 ? plan_splits(rows0, (int)w2_split_cap(n)) : sp;  // dW2
     // the output layer: matrix-core head with dW3 in registers (<= 16 classes), matrix-core head
     // plus a GEMM for dW3 (<= 64 classes), vector head (<= 32 classes, other hidden2), or GEMMs
     const bool h2_tiles = n->h2 == 64 || n->h2 == 128 || n->h2 == 256;
@@ -1577,7 +1655,7 @@ int net_accumulate(Net* n, const AccumArgs& a, hipStream_t s)
         SZ_HIP(hipGetLastError());
         // the ReLU derivative travels as one bit per unit
         uint32_t* relu_mask = w.mask;
-        rc = forward_hidden(n, w.xd, R, false, s, relu_mask, w.ldx);
+        rc = forward_hidden(n, w.xd, R, false, s, relu_mask, w.ldx, x3);
         if (rc) return rc;
         if (use_head) {
             HeadArgs h{};
@@ -1646,11 +1724,18 @@ int net_accumulate(Net* n, const AccumArgs& a, hipStream_t s)
         g.A = w.d2; g.lda = n->h2; g.B = w.w2t; g.ldb = n->h1; g.C = w.d1; g.ldc = n->h1;
         g.M = (int)R; g.N = n->h1; g.K = n->h2; g.k_chunk = n->h2; g.aux = w.h1; g.ldaux = n->h1;
         g.mask = relu_mask;
-        rc = relu_mask ? launch_gemm<A_ROWS, B_KROWS, EPI_MUL_MASK, T_DELTA1>(g, 1, s)
-                       : launch_gemm<A_ROWS, B_KROWS, EPI_MUL_DRELU, T_DELTA1>(g, 1, s);
+        if (x3) {  // B as [hidden1][hidden2] planes: w2 itself
+            g.B = (const float*)(w.w2s + 3 * ((uint64_t)n->h1 * n->h2 / 2)); g.ldb = n->h2;
+            g.b_plane = (uint64_t)n->h1 * n->h2;
+            rc = launch_gemm_x3<X3_ROWS_F32, X3_ROWS_SPLIT, EPI_MUL_MASK, T_DELTA1>(g, 1, s);
+        } else {
+            rc = relu_mask ? launch_gemm<A_ROWS, B_KROWS, EPI_MUL_MASK, T_DELTA1>(g, 1, s)
+                           : launch_gemm<A_ROWS, B_KROWS, EPI_MUL_DRELU, T_DELTA1>(g, 1, s);
+        }
         if (rc) return rc;
         // weight gradients: contractions over the rows ([w1|b1] in one launch via the ones row)
-        rc = grad_gemm<T_DW2>(w.h1, n->h1, w.d2, n->h2, n->h1, n->h2, R, w.slab + w.sl_w2, sp, add, false, s);
+        rc = x3 ? grad_gemm_x3<T_DW2>(w.h1, n->h1, w.d2, n->h2, n->h1, n->h2, R, w.slab + w.sl_w2, sp2, add, s)
+                : grad_gemm<T_DW2>(w.h1, n->h1, w.d2, n->h2, n->h1, n->h2, R, w.slab + w.sl_w2, sp2, add, false, s);
         if (rc) return rc;
         rc = grad_gemm<T_DW1>(w.xd, w.ldx, w.d1, n->h1, n->in + 1, n->h1, R, w.slab + w.sl_w1, sp1, add, false, s, true);
         if (rc) return rc;
@@ -1669,7 +1754,7 @@ int net_accumulate(Net* n, const AccumArgs& a, hipStream_t s)
         rc = reduce_slabs(w.slab + w.sl_b2, tail_slabs, n->h2, G + n->off_b2(), s);
         if (rc) return rc;
     }
-    rc = reduce_slabs(w.slab + w.sl_w2, sp.splits, (uint64_t)n->h1 * n->h2, G + n->off_w2(), s);
+    rc = reduce_slabs(w.slab + w.sl_w2, sp2.splits, (uint64_t)n->h1 * n->h2, G + n->off_w2(), s);
     if (rc) return rc;
     rc = reduce_slabs(w.slab + w.sl_w1, sp1.splits, (uint64_t)(n->in + 1) * n->h1, G + n->off_w1(), s);
     if (rc) return rc;

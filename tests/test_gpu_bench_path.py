@@ -32,8 +32,9 @@ def _oracle_grad_threads(onet, x, labels, threads=16):
     return np.sum(gs, axis=0)
 
 
+@pytest.mark.parametrize("gemm", ["f32", "bf16x3"])
 @pytest.mark.parametrize("dims,n", [((60, 512, 256, 16), 5000), ((60, 512, 256, 64), 3000)])
-def test_accumulate_dev_with_seeded_dropout_matches_oracle(sz, po, dims, n):
+def test_accumulate_dev_with_seeded_dropout_matches_oracle(sz, po, dims, n, gemm):
     """szh_net_accumulate_dev(dropout=0.2, seed) as bench.py calls it: the mask is rebuilt on the
     host from the same counter-based generator and the masked rows go to the oracle
     (lib.rs:119-129 no rescale, lib.rs:607-609 rows that end all-zero do not count)."""
@@ -43,6 +44,8 @@ def test_accumulate_dev_with_seeded_dropout_matches_oracle(sz, po, dims, n):
     params = [rng.uniform(-0.5, 0.5, s).astype(np.float32) for s in onet.shapes()]
     onet.set_params(params)
     net = sz.SimpleNeuralNet(*dims, init=params)
+    net.set_gemm(gemm)   # bf16x3: the three large products on the split-bf16 kernels, same tolerances
+    assert net.get_gemm() == gemm
     x = rng.standard_normal((n, 60)).astype(np.float32)
     x[11, 3:] = 0.0   # three non-zero inputs: some seeds drop all of them
     x[12] = 0.0
@@ -73,7 +76,8 @@ def test_accumulate_dev_with_seeded_dropout_matches_oracle(sz, po, dims, n):
     assert np.abs(grad_view(net).cpu().numpy()[:-2] - g[:-2]).max() > 1e-3 * scale
 
 
-def test_accumulate_dev_at_the_wide_configuration(sz, po):
+@pytest.mark.parametrize("gemm", ["f32", "bf16x3"])
+def test_accumulate_dev_at_the_wide_configuration(sz, po, gemm):
     """60-2048-2048-256 (the widest configuration): the chunked accumulate path with the GEMM output
     layer and the wave-per-row softmax, on 4 096 rows, against the oracle's gradient."""
     import torch
@@ -85,6 +89,7 @@ def test_accumulate_dev_at_the_wide_configuration(sz, po):
               for s in onet.shapes()]
     onet.set_params(params)
     net = sz.SimpleNeuralNet(*dims, init=params)
+    net.set_gemm(gemm)
     n = 4096
     x = rng.standard_normal((n, 60)).astype(np.float32)
     labels = rng.integers(0, 256, n).astype(np.int32)
@@ -98,8 +103,8 @@ def test_accumulate_dev_at_the_wide_configuration(sz, po):
     scale = np.abs(want).max()
     np.testing.assert_allclose(g[:-2], want, atol=3e-5 * scale)
     assert g[-1] == n
-    probs = onet.forward(x[:512])
-    np.testing.assert_allclose(net.forward(x[:512]), probs, atol=1e-4)
+    probs = onet.forward(x[:1280])   # >= 1024 rows, so that the forward pass also takes the chosen kernels
+    np.testing.assert_allclose(net.forward(x[:1280]), probs, atol=1e-4)
 
 
 def _shuffle_orders(seed, n_win, epochs):
