@@ -6,11 +6,9 @@
 // three dropped products are below 2^-24 of a.b, the rounding unit of an f32 product.  Six bf16
 // MFMAs do the work of eight v_mfma_f32_32x32x2_f32 at one sixteenth of their cost each.
 //
-// Block tile 128 x 128, four waves of 64 x 64, K tile 32.  Both operand tiles sit in LDS as three
-// bf16 planes [plane][row or column of the tile][k], k contiguous (row stride 40 bf16 = 80 bytes:
-// the 16-byte fragment reads of 16 consecutive rows cover all 64 banks once).  Splitting happens
-// once per element on the way into LDS; weights arrive pre-split from split_planes_kernel.  The
-// accumulator layout is that of the f32 kernel, so the epilogues are shared with it.
+// Splitting happens once per element on the way into LDS; weights arrive pre-split from
+// split_planes_kernel.  The accumulator layout is that of the f32 kernel (gemm_kernel.h), so the
+// epilogues are shared with it.
 #pragma once
 #include "gemm_kernel.h"
 
@@ -21,11 +19,6 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));  // a plain vector: arrays of it stay in registers
-
-constexpr int X3_KT = 32;
-constexpr int X3_LD = X3_KT + 8;        // bf16 per LDS row
-constexpr int X3_PLANE = BM * X3_LD;    // bf16 per plane of one operand tile
-constexpr int X3_TILE = 3 * X3_PLANE;
 
 enum X3Src {
     X3_ROWS_F32 = 0,   // f32 X[row][k]: the tile dimension runs over rows, k is contiguous
@@ -60,188 +53,6 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
     dst[plane_words + i] = m;
     dst[2 * plane_words + i] = l;
 }
-
-template <int SRC> struct X3Operand;
-
-template <> struct X3Operand<X3_ROWS_F32> {
-    float4 f[4];
-    // rows r0 .. r0+127 (clamped to r_max - 1: what such rows produce is never stored), k0 .. k0+31
-    __device__ __forceinline__ void load(const void* base, int ld, uint64_t, int r0, int r_max, int k0, int)
-    {
-        const float* b = (const float*)base;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int idx = threadIdx.x + 256 * i;
-            const int row = min(r0 + idx / 8, r_max - 1);
-            f[i] = *reinterpret_cast<const float4*>(b + (size_t)row * ld + k0 + 4 * (idx % 8));
-        }
-    }
-    __device__ __forceinline__ void stash(__bf16* S) const
-    {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int idx = threadIdx.x + 256 * i;
-            uint2 h, m, l;
-            split2(f[i].x, f[i].y, h.x, m.x, l.x);
-            split2(f[i].z, f[i].w, h.y, m.y, l.y);
-            __bf16* at = S + (idx / 8) * X3_LD + 4 * (idx % 8);
-            *reinterpret_cast<uint2*>(at) = h;
-            *reinterpret_cast<uint2*>(at + X3_PLANE) = m;
-            *reinterpret_cast<uint2*>(at + 2 * X3_PLANE) = l;
-        }
-    }
-};
-
-template <> struct X3Operand<X3_KROWS_F32> {
-    float f[16];
-    // columns c0 .. c0+127 (all exist), k rows k0 .. k0+31, zero from k_end on
-    __device__ __forceinline__ void load(const void* base, int ld, uint64_t, int c0, int, int k0, int k_end)
-    {
-        const float* b = (const float*)base + (size_t)(k0 + 16 * (threadIdx.x >> 7)) * ld + c0 + (threadIdx.x & 127);
-        if (k0 + X3_KT <= k_end) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) f[i] = b[(size_t)i * ld];
-        } else {
-            const int left = k_end - k0 - 16 * (int)(threadIdx.x >> 7);
-#pragma unroll
-            for (int i = 0; i < 16; ++i) f[i] = i < left ? b[(size_t)i * ld] : 0.0f;
-        }
-    }
-    __device__ __forceinline__ void stash(__bf16* S) const
-    {
-        uint32_t h[8], m[8], l[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) split2(f[2 * i], f[2 * i + 1], h[i], m[i], l[i]);
-        __bf16* at = S + (threadIdx.x & 127) * X3_LD + 16 * (threadIdx.x >> 7);
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            *reinterpret_cast<uint4*>(at + 8 * q) = make_uint4(h[4 * q], h[4 * q + 1], h[4 * q + 2], h[4 * q + 3]);
-            *reinterpret_cast<uint4*>(at + X3_PLANE + 8 * q) = make_uint4(m[4 * q], m[4 * q + 1], m[4 * q + 2], m[4 * q + 3]);
-            *reinterpret_cast<uint4*>(at + 2 * X3_PLANE + 8 * q) = make_uint4(l[4 * q], l[4 * q + 1], l[4 * q + 2], l[4 * q + 3]);
-        }
-    }
-};
-
-template <> struct X3Operand<X3_ROWS_SPLIT> {
-    u32x4 f[6];
-    // planes of `plane` bf16 each, rows r0 .. r0+127 (all exist) of ld values, k0 .. k0+31
-    __device__ __forceinline__ void load(const void* base, int ld, uint64_t plane, int r0, int, int k0, int)
-    {
-        const __bf16* b = (const __bf16*)base;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const int c = threadIdx.x + 256 * i;
-            f[i] = *reinterpret_cast<const u32x4*>(b + (size_t)(c >> 9) * plane + (size_t)(r0 + ((c & 511) >> 2)) * ld + k0 + 8 * (c & 3));
-        }
-    }
-    __device__ __forceinline__ void stash(__bf16* S) const
-    {
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const int c = threadIdx.x + 256 * i;
-            *reinterpret_cast<u32x4*>(S + (c >> 9) * X3_PLANE + ((c & 511) >> 2) * X3_LD + 8 * (c & 3)) = f[i];
-        }
-    }
-};
-
-// C[M][N] = epilogue(A . B) with the operands described by ASRC / BSRC:
-//   X3_ROWS_F32    A = g.A [M][K] (lda)            B = g.B [N][K] (ldb)
-//   X3_KROWS_F32   A = g.A [K][M] (lda)            B = g.B [K][N] (ldb)
-//   X3_ROWS_SPLIT                                   B = g.B planes [3][N][K] (ldb = K, g.b_plane apart)
-// Requirements checked by the host: the tile dimension of a KROWS or SPLIT operand is a multiple
-// of 128, K is a multiple of 32 unless both operands are KROWS (then k_chunk is), 16-byte aligned
-// rows for ROWS operands.
-template <int ASRC, int BSRC, int EPI, int TAG>
-__global__ __launch_bounds__(kGemmThreads) void gemm_x3_kernel(GemmArgs g)
-{
-    constexpr int TN = 2, WN = 64;
-    constexpr int DBG = TAG / 100;  // tuning harness only: 1 no MFMA, 2 no reloads, 4 no epilogue, 8 no stash
-    __shared__ __attribute__((aligned(16))) __bf16 As[X3_TILE];
-    __shared__ __attribute__((aligned(16))) __bf16 Bs[X3_TILE];
-    int bx, by, bz;
-    xcd_tile(bx, by, bz);
-    const int m0 = by * BM, n0 = bx * BN;
-    const int k_begin = bz * g.k_chunk;
-    const int k_end = min(g.K, k_begin + g.k_chunk);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int l31 = lane & 31, half = lane >> 5;
-
-    float* C = g.C;
-    if (EPI == EPI_SLAB) C += (size_t)bz * (size_t)g.M * (size_t)g.ldc;
-    f32x16 acc[2][TN];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-    if (EPI == EPI_SLAB && g.slab_add) {
-#pragma unroll
-        for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-            for (int tn = 0; tn < TN; ++tn) {
-                const int col = n0 + wn * WN + tn * 32 + l31;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = m0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    acc[tm][tn][r] = C[(size_t)row * g.ldc + col];
-                }
-            }
-    }
-
-    X3Operand<ASRC> fa;
-    X3Operand<BSRC> fb;
-    if (k_begin < k_end) {
-        fa.load(g.A, g.lda, 0, m0, g.M, k_begin, k_end);
-        fb.load(g.B, g.ldb, g.b_plane, n0, g.N, k_begin, k_end);
-    }
-    const __bf16* ar = As + (wm * 64 + l31) * X3_LD + 8 * half;
-    const __bf16* br = Bs + (wn * 64 + l31) * X3_LD + 8 * half;
-    for (int k0 = k_begin; k0 < k_end; k0 += X3_KT) {
-        __syncthreads();
-        if (!(DBG & 8) || k0 == k_begin) {
-            fa.stash(As);
-            fb.stash(Bs);
-        }
-        __syncthreads();
-        if (k0 + X3_KT < k_end && !(DBG & 2)) {
-            fa.load(g.A, g.lda, 0, m0, g.M, k0 + X3_KT, k_end);
-            fb.load(g.B, g.ldb, g.b_plane, n0, g.N, k0 + X3_KT, k_end);
-        }
-        if (DBG & 1) continue;
-#pragma unroll
-        for (int ks = 0; ks < X3_KT / 16; ++ks) {
-            bf16x8 a[2][3], b[TN][3];
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int p = 0; p < 3; ++p) {
-                    a[t][p] = *reinterpret_cast<const bf16x8*>(ar + p * X3_PLANE + t * 32 * X3_LD + 16 * ks);
-                    b[t][p] = *reinterpret_cast<const bf16x8*>(br + p * X3_PLANE + t * 32 * X3_LD + 16 * ks);
-                }
-#pragma unroll
-            for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-                for (int tn = 0; tn < TN; ++tn) {
-                    f32x16 c = acc[tm][tn];
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][2], b[tn][0], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][0], b[tn][2], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][1], b[tn][1], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][1], b[tn][0], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][0], b[tn][1], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][0], b[tn][0], c, 0, 0, 0);
-                    acc[tm][tn] = c;
-                }
-        }
-    }
-    if (DBG & 4) {
-        if (acc[0][0][0] + acc[1][1][5] + acc[0][1][3] + acc[1][0][9] == 12345.678f) C[threadIdx.x] = 1.0f;
-        return;
-    }
-    finish_tile<EPI, BM, TN, WN>(g, C, acc, m0, n0, wm, wn, l31, half);
-}
-
 
 // ---- 256 x 256 block tile ------------------------------------------------------------------
 // Eight waves (4 x 2, each 64 rows x 128 columns = 2 x 4 MFMA tiles), one workgroup per compute
@@ -288,20 +99,13 @@ template <> struct XWOperand<X3_ROWS_F32> {
 
 template <> struct XWOperand<X3_KROWS_F32> {
     float f[16];  // f[8 h + j]: column t % 256, k = 16 h + 8 (t / 256) + j
-    __device__ __forceinline__ void load(const void* base, int ld, uint64_t, int c0, int, int k0, int k_end)
+    // all 32 rows are read: the caller keeps zeros in the rows between the end of the data and
+    // the next multiple of 32
+    __device__ __forceinline__ void load(const void* base, int ld, uint64_t, int c0, int, int k0, int)
     {
-        const int kb = k0 + 8 * (int)(threadIdx.x >> 8);
-        const float* b = (const float*)base + (size_t)kb * ld + c0 + (threadIdx.x & 255);
-        if (k0 + 32 <= k_end) {
+        const float* b = (const float*)base + (size_t)(k0 + 8 * (int)(threadIdx.x >> 8)) * ld + c0 + (threadIdx.x & 255);
 #pragma unroll
-            for (int i = 0; i < 16; ++i) f[i] = b[(size_t)(16 * (i >> 3) + (i & 7)) * ld];
-        } else {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int k = 16 * (i >> 3) + (i & 7);
-                f[i] = kb + k < k_end ? b[(size_t)k * ld] : 0.0f;
-            }
-        }
+        for (int i = 0; i < 16; ++i) f[i] = b[(size_t)(16 * (i >> 3) + (i & 7)) * ld];
     }
     template <int H> __device__ __forceinline__ void stash(__bf16* S) const
     {
@@ -333,122 +137,146 @@ template <> struct XWOperand<X3_ROWS_SPLIT> {
     }
 };
 
-// Same operands and epilogues as gemm_x3_kernel.  Requirements checked by the host: N and, for a
-// KROWS A, M are multiples of 256; the K range of every grid z index is a multiple of 32 long
-// (rows past K read as zero for KROWS operands); g.lda / g.ldb rows 16-byte aligned.
+// C[M][N] = epilogue(A . B) with the operands described by ASRC / BSRC:
+//   X3_ROWS_F32    A = g.A [M][K] (lda)
+//   X3_KROWS_F32   A = g.A [K][M] (lda)            B = g.B [K][N] (ldb)
+//   X3_ROWS_SPLIT                                   B = g.B planes [3][N][K] (ldb = K, g.b_plane apart)
+// Requirements checked by the host: N and, for a KROWS A, M are multiples of 256; the K range of
+// every grid z index is a multiple of 32 long and KROWS operands hold zeros in the rows from K to the
+// next multiple of 32;
+// g.lda / g.ldb rows 16-byte aligned.
+//
+// The grid is one-dimensional and a workgroup walks over tiles  first, first + stride, ...  of the
+// g.tiles_x * g.tiles_y * g.tiles_z tiles (x fastest).  The operand pipeline runs across tiles: the
+// last trip of a tile fetches the first 32 k of the next one, so a tile's epilogue sits between two
+// trips with the next operands already in LDS and in registers, and its stores drain under the
+// next tile's first steps (with one workgroup per compute unit nothing else would hide them).
 template <int ASRC, int BSRC, int EPI, int TAG>
 __global__ __launch_bounds__(XW_THREADS) void gemm_x3w_kernel(GemmArgs g)
 {
     constexpr int TN = 4, WN = 128;
-    constexpr int DBG = TAG / 100;  // tuning harness only: 1 no MFMA, 2 no reloads, 4 no epilogue, 8 no stash
     extern __shared__ __attribute__((aligned(16))) unsigned char xw_lds[];
     __bf16* L = reinterpret_cast<__bf16*>(xw_lds);
-    int bx, by, bz;
-    xcd_tile(bx, by, bz);
-    const int m0 = by * XW_TM, n0 = bx * XW_TN;
-    const int k_begin = bz * g.k_chunk;
-    const int k_end = min(g.K, k_begin + g.k_chunk);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int l31 = lane & 31, half = lane >> 5;
+    const int a_off = (wm * 64 + l31) * XW_LD + 8 * half;
+    const int b_off = XW_OPER + (wn * WN + l31) * XW_LD + 8 * half;
 
-    float* C = g.C;
-    if (EPI == EPI_SLAB) C += (size_t)bz * (size_t)g.M * (size_t)g.ldc;
-    f32x16 acc[2][TN];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-    if (EPI == EPI_SLAB && g.slab_add) {
-#pragma unroll
-        for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-            for (int tn = 0; tn < TN; ++tn) {
-                const int col = n0 + wn * WN + tn * 32 + l31;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = m0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    acc[tm][tn][r] = C[(size_t)row * g.ldc + col];
-                }
-            }
-    }
-    if (k_begin >= k_end) {
-        finish_tile<EPI, XW_TM, TN, WN>(g, C, acc, m0, n0, wm, wn, l31, half);
-        return;
-    }
+    // Tiles are numbered so that each XCD (workgroups go to the 8 XCDs round-robin in launch
+    // order) works on one contiguous run of them: neighbours that share operand rows share one L2.
+    const int n_tiles = g.tiles_x * g.tiles_y * g.tiles_z;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd = (int)gridDim.x >> 3;
+    const int run = (n_tiles + 7) >> 3;           // tiles per XCD
+    const int run_end = min(n_tiles, (xcd + 1) * run);
+    int tile = xcd * run + slot;
+    if (tile >= run_end) return;
+    struct Pos { int m0, n0, k_begin, k_end, bz; };
+    auto place = [&](int t) {
+        Pos p;
+        const int bx = t % g.tiles_x, by = (t / g.tiles_x) % g.tiles_y;
+        p.bz = t / (g.tiles_x * g.tiles_y);
+        p.m0 = by * XW_TM; p.n0 = bx * XW_TN;
+        p.k_begin = p.bz * g.k_chunk;
+        p.k_end = min(g.K, p.k_begin + g.k_chunk);
+        return p;
+    };
+    Pos cur = place(tile);
 
     XWOperand<ASRC> fa;
     XWOperand<BSRC> fb;
-    fa.load(g.A, g.lda, 0, m0, g.M, k_begin, k_end);
-    fb.load(g.B, g.ldb, g.b_plane, n0, g.N, k_begin, k_end);
+    fa.load(g.A, g.lda, 0, cur.m0, g.M, cur.k_begin, cur.k_end);
+    fb.load(g.B, g.ldb, g.b_plane, cur.n0, g.N, cur.k_begin, cur.k_end);
     fa.template stash<0>(L);
     fb.template stash<0>(L + XW_OPER);
     __syncthreads();
-    const int a_off = (wm * 64 + l31) * XW_LD + 8 * half;
-    const int b_off = XW_OPER + (wn * WN + l31) * XW_LD + 8 * half;
-    bf16x8 a[2][3];
-    auto load_a = [&](const __bf16* S) {
+
+    while (true) {
+        float* C = g.C;
+        if (EPI == EPI_SLAB) C += (size_t)cur.bz * (size_t)g.M * (size_t)g.ldc;
+        f32x16 acc[2][TN];
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int p = 0; p < 3; ++p) a[t][p] = *reinterpret_cast<const bf16x8*>(S + a_off + p * XW_PLANE + t * 32 * XW_LD);
-    };
-    auto multiply = [&](const __bf16* S, int tn0) {  // column tiles tn0, tn0 + 1
-        if (DBG & 1) return;
+            for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int tn = tn0; tn < tn0 + 2; ++tn) {
-            bf16x8 b[3];
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+        if (EPI == EPI_SLAB && g.slab_add) {
 #pragma unroll
-            for (int p = 0; p < 3; ++p) b[p] = *reinterpret_cast<const bf16x8*>(S + b_off + p * XW_PLANE + tn * 32 * XW_LD);
+            for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
-            for (int tm = 0; tm < 2; ++tm) {
-                f32x16 c = acc[tm][tn];
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][2], b[0], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][0], b[2], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][1], b[1], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][1], b[0], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][0], b[1], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][0], b[0], c, 0, 0, 0);
-                acc[tm][tn] = c;
-            }
+                for (int tn = 0; tn < TN; ++tn) {
+                    const int col = cur.n0 + wn * WN + tn * 32 + l31;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = cur.m0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                        acc[tm][tn][r] = C[(size_t)row * g.ldc + col];
+                    }
+                }
         }
-    };
-    // two 16-k steps per trip: the registers hold the 32 k starting at k0
-    for (int k0 = k_begin; k0 < k_end; k0 += 32) {
-        // step 0 reads stage 0; stage 1 receives the second half of the register tile, after
-        // which the registers are free for the next 32 k
-        const bool more = k0 + 32 < k_end;
-        load_a(L);
-        if (!(DBG & 8)) {
+        const int next = tile + per_xcd;
+        const bool has_next = next < run_end;
+        const Pos nxt = has_next ? place(next) : cur;
+
+        bf16x8 a[2][3];
+        auto load_a = [&](const __bf16* S) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) a[t][p] = *reinterpret_cast<const bf16x8*>(S + a_off + p * XW_PLANE + t * 32 * XW_LD);
+        };
+        auto multiply = [&](const __bf16* S, int tn0) {  // column tiles tn0, tn0 + 1
+#pragma unroll
+            for (int tn = tn0; tn < tn0 + 2; ++tn) {
+                bf16x8 b[3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) b[p] = *reinterpret_cast<const bf16x8*>(S + b_off + p * XW_PLANE + tn * 32 * XW_LD);
+#pragma unroll
+                for (int tm = 0; tm < 2; ++tm) {
+                    f32x16 c = acc[tm][tn];
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][2], b[0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][0], b[2], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][1], b[1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][1], b[0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][0], b[1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][0], b[0], c, 0, 0, 0);
+                    acc[tm][tn] = c;
+                }
+            }
+        };
+        // Two 16-k steps per trip.  On entry the registers hold the 32 k starting at k0 and their
+        // first half is in stage 0.
+        for (int k0 = cur.k_begin; k0 < cur.k_end; k0 += 32) {
+            // what this trip fetches: the tile's next 32 k; on its last trip the first 32 k of the
+            // next tile; on the workgroup's very last trip its own range again (never used)
+            const bool last = k0 + 32 >= cur.k_end;
+            const int fm0 = last ? nxt.m0 : cur.m0, fn0 = last ? nxt.n0 : cur.n0;
+            const int fk = last ? (has_next ? nxt.k_begin : k0) : k0 + 32, fk_end = last ? nxt.k_end : cur.k_end;
+            // step 0 reads stage 0; stage 1 receives the second half of the register tile, after
+            // which the registers are free for the next fetch
+            load_a(L);
             fa.template stash<1>(L + XW_STAGE);
             fb.template stash<1>(L + XW_STAGE + XW_OPER);
-        }
-        if (more && !(DBG & 2)) {
-            fa.load(g.A, g.lda, 0, m0, g.M, k0 + 32, k_end);
-            fb.load(g.B, g.ldb, g.b_plane, n0, g.N, k0 + 32, k_end);
-        }
-        multiply(L, 0);
-        multiply(L, 2);
-        __syncthreads();
-        // step 1 reads stage 1; stage 0 receives the first half of the next register tile, as
-        // late as possible: its loads were issued one step ago
-        load_a(L + XW_STAGE);
-        multiply(L + XW_STAGE, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (more && !(DBG & 8)) {
+            fa.load(g.A, g.lda, 0, fm0, g.M, fk, fk_end);
+            fb.load(g.B, g.ldb, g.b_plane, fn0, g.N, fk, fk_end);
+            multiply(L, 0);
+            multiply(L, 2);
+            __syncthreads();
+            // step 1 reads stage 1; stage 0 receives the first half of the fetched registers in
+            // the step's second half: their loads were issued one step ago
+            load_a(L + XW_STAGE);
+            multiply(L + XW_STAGE, 0);
+            __builtin_amdgcn_sched_barrier(0);
             fa.template stash<0>(L);
             fb.template stash<0>(L + XW_OPER);
+            multiply(L + XW_STAGE, 2);
+            __syncthreads();
         }
-        multiply(L + XW_STAGE, 2);
-        __syncthreads();
+        finish_tile<EPI, XW_TM, TN, WN>(g, C, acc, cur.m0, cur.n0, wm, wn, l31, half);
+        if (!has_next) break;
+        tile = next;
+        cur = nxt;
     }
-    if (DBG & 4) {
-        if (acc[0][0][0] + acc[1][1][5] + acc[0][3][3] + acc[1][2][9] == 12345.678f) C[threadIdx.x] = 1.0f;
-        return;
-    }
-    finish_tile<EPI, XW_TM, TN, WN>(g, C, acc, m0, n0, wm, wn, l31, half);
 }
 
 }  // namespace gemm

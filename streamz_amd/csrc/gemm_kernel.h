@@ -55,6 +55,7 @@ struct GemmArgs {
     uint32_t* mask = nullptr;  // EPI_*_MASK: [ceil(M / 32)][N] sign bits of the ReLU layer, one word per
                                // column and block of 32 rows (what one lane of an MFMA tile holds)
     uint64_t b_plane = 0;      // split-bf16 kernel: elements between the three planes of a pre-split B
+    int tiles_x = 0, tiles_y = 0, tiles_z = 0;  // split-bf16 kernel: tiles along N, M and the K ranges
 };
 
 struct Frag4 { float v[4]; };
@@ -191,9 +192,11 @@ __device__ __forceinline__ void xcd_tile(int& bx, int& by, int& bz)
 
 // Epilogue shared by the kernels whose accumulators have the 32x32 MFMA layout: a lane holds
 // column `col` of a tile and the 16 rows (r & 3) + 8 (r >> 2) + 4 half.
+// First pass: bias / activation / derivative applied in place (finish_values); second pass: the
+// stores (store_tile).  finish_tile is the two in a row.
 template <int EPI, int TM, int TN, int WN>
-__device__ __forceinline__ void finish_tile(const GemmArgs& g, float* C, f32x16 (&acc)[2][TN], int m0, int n0, int wm, int wn,
-                                            int l31, int half)
+__device__ __forceinline__ void finish_values(const GemmArgs& g, f32x16 (&acc)[2][TN], int m0, int n0, int wm, int wn, int l31,
+                                              int half)
 {
     // One MFMA tile is 32 rows x 32 columns; a lane holds column `col` and the 16 rows
     // (r & 3) + 8 (r >> 2) + 4 half.  Its 16 sign bits and those of lane ^ 32 make the mask word
@@ -244,8 +247,14 @@ __device__ __forceinline__ void finish_tile(const GemmArgs& g, float* C, f32x16 
                 acc[tm][tn][r] = v;
             }
         }
-    // Second pass: the stores.  Every value was finished above, in place, so everything the
-    // epilogue loads has arrived before the first store and the stores go out back to back.
+}
+
+// Every value was finished in place by finish_values, so everything the epilogue loads has arrived
+// before the first store and the stores go out back to back.
+template <int EPI, int TM, int TN, int WN>
+__device__ __forceinline__ void store_tile(const GemmArgs& g, float* C, const f32x16 (&acc)[2][TN], int m0, int n0, int wm,
+                                           int wn, int l31, int half)
+{
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
@@ -265,6 +274,14 @@ __device__ __forceinline__ void finish_tile(const GemmArgs& g, float* C, f32x16 
                 }
             }
         }
+}
+
+template <int EPI, int TM, int TN, int WN>
+__device__ __forceinline__ void finish_tile(const GemmArgs& g, float* C, f32x16 (&acc)[2][TN], int m0, int n0, int wm, int wn,
+                                            int l31, int half)
+{
+    finish_values<EPI, TM, TN, WN>(g, acc, m0, n0, wm, wn, l31, half);
+    store_tile<EPI, TM, TN, WN>(g, C, acc, m0, n0, wm, wn, l31, half);
 }
 
 // TAG only separates instantiations, so that each call site is its own kernel in a profile.

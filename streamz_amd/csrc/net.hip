@@ -53,6 +53,18 @@ int launch_gemm(GemmArgs g, int splits, hipStream_t s)
     return SZH_OK;
 }
 
+int compute_units()
+{
+    static int cus[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (cus[dev] == 0) {
+        int v = 0;
+        cus[dev] = hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v >= 8 ? v : 256;
+    }
+    return cus[dev];
+}
+
 // The three large products of a training chunk on the bf16 matrix cores with every f32 operand
 // split exactly into three bf16 pieces (gemm_bf16x3.h).
 template <int ASRC, int BSRC, int EPI, int TAG>
@@ -61,8 +73,11 @@ int launch_gemm_x3(GemmArgs g, int splits, hipStream_t s)
     if (g.M <= 0 || g.N <= 0) return SZH_OK;
     if (int rc = allow_dynamic_lds((const void*)gemm_x3w_kernel<ASRC, BSRC, EPI, TAG>, XW_LDS_BYTES)) return rc;
     ProfScope prof(kGemmTagName[TAG], s);
-    dim3 grid((g.N + XW_TN - 1) / XW_TN, (g.M + XW_TM - 1) / XW_TM, splits);
-    hipLaunchKernelGGL((gemm_x3w_kernel<ASRC, BSRC, EPI, TAG>), grid, dim3(XW_THREADS), XW_LDS_BYTES, s, g);
+    g.tiles_x = (g.N + XW_TN - 1) / XW_TN; g.tiles_y = (g.M + XW_TM - 1) / XW_TM; g.tiles_z = splits;
+    // one workgroup per compute unit (its LDS use allows no second one), a multiple of the 8 XCDs
+    const int tiles = g.tiles_x * g.tiles_y * g.tiles_z;
+    const int blocks = std::min((tiles + 7) / 8 * 8, compute_units() / 8 * 8);
+    hipLaunchKernelGGL((gemm_x3w_kernel<ASRC, BSRC, EPI, TAG>), dim3(blocks), dim3(XW_THREADS), XW_LDS_BYTES, s, g);
     SZ_HIP(hipGetLastError());
     return SZH_OK;
 }
@@ -1277,10 +1292,12 @@ int ensure_workspace(Net* n, uint64_t rows)
     // prepared rows are padded to a whole tile of columns: [x | 1 | 0...]
     w.ldx = n->in + 1 <= 64 ? 64 : (int)((n->in + 1 + 127) / 128 * 128);
     SZ_HIP(hipMalloc((void**)&w.xd, R * w.ldx * sizeof(float)));
-    SZ_HIP(hipMalloc((void**)&w.h1, R * n->h1 * sizeof(float)));
+    // h1 and d2 carry 32 rows of slack: the split-bf16 weight-gradient kernel reads whole groups of
+    // 32 rows and wants zeros behind the last one
+    SZ_HIP(hipMalloc((void**)&w.h1, (R + 32) * n->h1 * sizeof(float)));
     SZ_HIP(hipMalloc((void**)&w.h2, R * n->h2 * sizeof(float)));
     SZ_HIP(hipMalloc((void**)&w.p, R * (n->out ? n->out : 1) * sizeof(float)));
-    SZ_HIP(hipMalloc((void**)&w.d2, R * n->h2 * sizeof(float)));
+    SZ_HIP(hipMalloc((void**)&w.d2, (R + 32) * n->h2 * sizeof(float)));
     SZ_HIP(hipMalloc((void**)&w.d1, R * n->h1 * sizeof(float)));
     SZ_HIP(hipMalloc((void**)&w.slab, w.slab_floats * sizeof(float)));
     SZ_HIP(hipMalloc((void**)&w.live, R));
@@ -1734,6 +1751,11 @@ int net_accumulate(Net* n, const AccumArgs& a, hipStream_t s)
         }
         if (rc) return rc;
         // weight gradients: contractions over the rows ([w1|b1] in one launch via the ones row)
+        if (x3 && R % 32) {  // zero rows up to the next multiple of 32
+            const uint64_t pad = 32 - R % 32;
+            SZ_HIP(hipMemsetAsync(w.h1 + R * n->h1, 0, pad * n->h1 * sizeof(float), s));
+            SZ_HIP(hipMemsetAsync(w.d2 + R * n->h2, 0, pad * n->h2 * sizeof(float), s));
+        }
         rc = x3 ? grad_gemm_x3<T_DW2>(w.h1, n->h1, w.d2, n->h2, n->h1, n->h2, R, w.slab + w.sl_w2, sp2, add, s)
                 : grad_gemm<T_DW2>(w.h1, n->h1, w.d2, n->h2, n->h1, n->h2, R, w.slab + w.sl_w2, sp2, add, false, s);
         if (rc) return rc;

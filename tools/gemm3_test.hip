@@ -1,6 +1,7 @@
 // Correctness and timing harness of the split-bf16 GEMM (streamz_amd/csrc/gemm_bf16x3.h) next to the
 // f32 kernel, on the three large products of a training chunk.  Not part of the library.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Istreamz_amd/csrc -o tools/bin/gemm3_test tools/gemm3_test.hip
+//   tools/bin/gemm3_test [rows for the timing part] [hidden1] [hidden2]
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -41,11 +42,15 @@ double maxerr(const std::vector<float>& got, const std::vector<double>& ref)
     return e;
 }
 
-void wide_attr()
+template <int ASRC, int BSRC, int EPI, int TAG = 0>
+void launch_w(GemmArgs g, int splits, int max_blocks = 256)
 {
-    CK(hipFuncSetAttribute((const void*)gemm_x3w_kernel<X3_ROWS_F32, X3_ROWS_SPLIT, EPI_BIAS_TANH, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)XW_LDS_BYTES));
-    CK(hipFuncSetAttribute((const void*)gemm_x3w_kernel<X3_ROWS_F32, X3_ROWS_SPLIT, EPI_MUL_DRELU, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)XW_LDS_BYTES));
-    CK(hipFuncSetAttribute((const void*)gemm_x3w_kernel<X3_KROWS_F32, X3_KROWS_F32, EPI_SLAB, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)XW_LDS_BYTES));
+    static bool once = false;
+    if (!once) { CK(hipFuncSetAttribute((const void*)gemm_x3w_kernel<ASRC, BSRC, EPI, TAG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)XW_LDS_BYTES)); once = true; }
+    g.tiles_x = (g.N + 255) / 256; g.tiles_y = (g.M + 255) / 256; g.tiles_z = splits;
+    const int tiles = g.tiles_x * g.tiles_y * g.tiles_z;
+    const int blocks = std::min((tiles + 7) / 8 * 8, max_blocks);
+    hipLaunchKernelGGL((gemm_x3w_kernel<ASRC, BSRC, EPI, TAG>), dim3(blocks), dim3(XW_THREADS), XW_LDS_BYTES, 0, g);
 }
 
 template <class K> float time_us(K launch, int iters)
@@ -67,15 +72,16 @@ int main(int argc, char** argv)
 {
     const int H1 = argc > 2 ? std::atoi(argv[2]) : 512, H2 = argc > 3 ? std::atoi(argv[3]) : 256;
     const int big = argc > 1 ? std::atoi(argv[1]) : 0;
-    {   // ---- correctness on a ragged row count ----
-        const int R = 1000 + 37;
+    {   // ---- correctness on a ragged row count: three row tiles per workgroup-walk and a partial last tile ----
+        const int R = 256 * 20 + 37;  // 21 row tiles on 8 workgroups: every workgroup walks over several
         auto h1 = rnd((size_t)R * H1, 3.0f, 1, true), w2 = rnd((size_t)H1 * H2, 0.5f, 2), b2 = rnd(H2, 0.1f, 3);
         auto d2 = rnd((size_t)R * H2, 1.0f, 4);
         std::vector<float> w2t((size_t)H1 * H2);
         for (int k = 0; k < H1; ++k) for (int n = 0; n < H2; ++n) w2t[(size_t)n * H1 + k] = w2[(size_t)k * H2 + n];
+        h1.resize((size_t)(R + 32) * H1, 0.0f); d2.resize((size_t)(R + 32) * H2, 0.0f);  // zero rows up to the next multiple of 32
         float *dh1 = upload(h1), *dw2 = upload(w2), *dw2t = upload(w2t), *db2 = upload(b2), *dd2 = upload(d2);
-        float *dh2 = dev<float>((size_t)R * H2), *dh2x = dev<float>((size_t)R * H2);
-        float *dd1 = dev<float>((size_t)R * H1), *dd1x = dev<float>((size_t)R * H1);
+        float *dh2 = dev<float>((size_t)R * H2), *dh2w = dev<float>((size_t)R * H2);
+        float *dd1 = dev<float>((size_t)R * H1), *dd1w = dev<float>((size_t)R * H1);
         uint32_t* w2t3 = split_dev(dw2t, (size_t)H1 * H2);  // [3][H2][H1]: B of fwd2 as [n][k]
         uint32_t* w23 = split_dev(dw2, (size_t)H1 * H2);    // [3][H1][H2]: B of delta1 as [n][k]
         // fwd2: h2 = tanh(h1 . w2 + b2)
@@ -83,37 +89,23 @@ int main(int argc, char** argv)
         g.A = dh1; g.lda = H1; g.B = dw2; g.ldb = H2; g.C = dh2; g.ldc = H2; g.M = R; g.N = H2; g.K = H1; g.k_chunk = H1; g.bias = db2; g.a_vec = 1; g.b_vec = 1;
         dim3 grid(H2 / 128, (R + 127) / 128, 1);
         hipLaunchKernelGGL((gemm_kernel<A_ROWS, B_KROWS, EPI_BIAS_TANH, 0, 128, 32, 0>), grid, dim3(256), 0, 0, g);
-        GemmArgs gx = g; gx.C = dh2x; gx.B = (const float*)w2t3; gx.ldb = H1; gx.b_plane = (uint64_t)H1 * H2;
-        hipLaunchKernelGGL((gemm_x3_kernel<X3_ROWS_F32, X3_ROWS_SPLIT, EPI_BIAS_TANH, 0>), grid, dim3(256), 0, 0, gx);
+        GemmArgs gw = g; gw.C = dh2w; gw.B = (const float*)w2t3; gw.ldb = H1; gw.b_plane = (uint64_t)H1 * H2;
+        launch_w<X3_ROWS_F32, X3_ROWS_SPLIT, EPI_BIAS_TANH>(gw, 1, 8);
         CK(hipDeviceSynchronize());
-        float* dh2w = dev<float>((size_t)R * H2);
-        GemmArgs gw_ = gx; gw_.C = dh2w;
-        wide_attr();
-        hipLaunchKernelGGL((gemm_x3w_kernel<X3_ROWS_F32, X3_ROWS_SPLIT, EPI_BIAS_TANH, 0>), dim3(H2 / 256, (R + 255) / 256, 1), dim3(512), XW_LDS_BYTES, 0, gw_);
-        CK(hipDeviceSynchronize());
-        std::vector<double> ref((size_t)R * H2), refpre((size_t)R * H2);
+        std::vector<double> ref((size_t)R * H2);
         for (int r = 0; r < R; ++r) for (int n = 0; n < H2; ++n) {
             double s = b2[n];
             for (int k = 0; k < H1; ++k) s += (double)h1[(size_t)r * H1 + k] * w2[(size_t)k * H2 + n];
-            refpre[(size_t)r * H2 + n] = s; ref[(size_t)r * H2 + n] = std::tanh(s);
+            ref[(size_t)r * H2 + n] = std::tanh(s);
         }
-        std::printf("fwd2   (tanh out)  max |err| vs f64: f32 kernel %.3e   bf16x3 kernel %.3e   wide %.3e\n", maxerr(download(dh2, ref.size()), ref), maxerr(download(dh2x, ref.size()), ref), maxerr(download(dh2w, ref.size()), ref));
-        // the same product without the tanh, which hides absolute error of large sums
-        hipLaunchKernelGGL((gemm_kernel<A_ROWS, B_KROWS, EPI_BIAS, 0, 128, 32, 0>), grid, dim3(256), 0, 0, g);
-        hipLaunchKernelGGL((gemm_x3_kernel<X3_ROWS_F32, X3_ROWS_SPLIT, EPI_BIAS, 0>), grid, dim3(256), 0, 0, gx);
-        CK(hipDeviceSynchronize());
-        double mag = 0; for (double v : refpre) mag = std::fmax(mag, std::fabs(v));
-        std::printf("fwd2   (pre-act, max |value| %.1f)  f32 kernel %.3e   bf16x3 kernel %.3e\n", mag, maxerr(download(dh2, ref.size()), refpre), maxerr(download(dh2x, ref.size()), refpre));
+        std::printf("fwd2   (tanh out)  max |err| vs f64: f32 kernel %.3e   bf16x3 kernel %.3e\n", maxerr(download(dh2, ref.size()), ref), maxerr(download(dh2w, ref.size()), ref));
         // delta1 = (d2 . w2^T) * [h1 > 0]
         g = GemmArgs{};
         g.A = dd2; g.lda = H2; g.B = dw2t; g.ldb = H1; g.C = dd1; g.ldc = H1; g.M = R; g.N = H1; g.K = H2; g.k_chunk = H2; g.aux = dh1; g.ldaux = H1; g.a_vec = 1; g.b_vec = 1;
         grid = dim3(H1 / 128, (R + 127) / 128, 1);
         hipLaunchKernelGGL((gemm_kernel<A_ROWS, B_KROWS, EPI_MUL_DRELU, 0, 128, 32, 0>), grid, dim3(256), 0, 0, g);
-        gx = g; gx.C = dd1x; gx.B = (const float*)w23; gx.ldb = H2; gx.b_plane = (uint64_t)H1 * H2;
-        hipLaunchKernelGGL((gemm_x3_kernel<X3_ROWS_F32, X3_ROWS_SPLIT, EPI_MUL_DRELU, 0>), grid, dim3(256), 0, 0, gx);
-        float* dd1w = dev<float>((size_t)R * H1);
-        gw_ = gx; gw_.C = dd1w;
-        hipLaunchKernelGGL((gemm_x3w_kernel<X3_ROWS_F32, X3_ROWS_SPLIT, EPI_MUL_DRELU, 0>), dim3(H1 / 256, (R + 255) / 256, 1), dim3(512), XW_LDS_BYTES, 0, gw_);
+        gw = g; gw.C = dd1w; gw.B = (const float*)w23; gw.ldb = H2; gw.b_plane = (uint64_t)H1 * H2;
+        launch_w<X3_ROWS_F32, X3_ROWS_SPLIT, EPI_MUL_DRELU>(gw, 1, 16);
         CK(hipDeviceSynchronize());
         std::vector<double> ref1((size_t)R * H1);
         for (int r = 0; r < R; ++r) for (int n = 0; n < H1; ++n) {
@@ -121,21 +113,18 @@ int main(int argc, char** argv)
             for (int k = 0; k < H2; ++k) s += (double)d2[(size_t)r * H2 + k] * w2[(size_t)n * H2 + k];
             ref1[(size_t)r * H1 + n] = h1[(size_t)r * H1 + n] > 0 ? s : 0.0;
         }
-        std::printf("delta1 max |err| vs f64: f32 kernel %.3e   bf16x3 kernel %.3e   wide %.3e\n", maxerr(download(dd1, ref1.size()), ref1), maxerr(download(dd1x, ref1.size()), ref1), maxerr(download(dd1w, ref1.size()), ref1));
+        std::printf("delta1 max |err| vs f64: f32 kernel %.3e   bf16x3 kernel %.3e\n", maxerr(download(dd1, ref1.size()), ref1), maxerr(download(dd1w, ref1.size()), ref1));
         // dw2 = h1^T . d2 in split-K slabs, second call adds
         const int kc = 288, splits = (R + kc - 1) / kc;
-        float *slab = dev<float>((size_t)splits * H1 * H2), *slabx = dev<float>((size_t)splits * H1 * H2);
+        float *slab = dev<float>((size_t)splits * H1 * H2), *slabw = dev<float>((size_t)splits * H1 * H2);
         g = GemmArgs{};
         g.A = dh1; g.lda = H1; g.B = dd2; g.ldb = H2; g.C = slab; g.ldc = H2; g.M = H1; g.N = H2; g.K = R; g.k_chunk = kc; g.a_vec = 1; g.b_vec = 1;
         grid = dim3(H2 / 128, H1 / 128, splits);
-        gx = g; gx.C = slabx;
-        float* slabw = dev<float>((size_t)splits * H1 * H2);
-        gw_ = g; gw_.C = slabw;
+        gw = g; gw.C = slabw;
         for (int pass = 0; pass < 2; ++pass) {
-            g.slab_add = gx.slab_add = gw_.slab_add = pass;
-            hipLaunchKernelGGL((gemm_x3w_kernel<X3_KROWS_F32, X3_KROWS_F32, EPI_SLAB, 0>), dim3(H2 / 256, H1 / 256, splits), dim3(512), XW_LDS_BYTES, 0, gw_);
+            g.slab_add = gw.slab_add = pass;
             hipLaunchKernelGGL((gemm_kernel<A_KROWS, B_KROWS, EPI_SLAB, 0, 128, 32, 0>), grid, dim3(256), 0, 0, g);
-            hipLaunchKernelGGL((gemm_x3_kernel<X3_KROWS_F32, X3_KROWS_F32, EPI_SLAB, 0>), grid, dim3(256), 0, 0, gx);
+            launch_w<X3_KROWS_F32, X3_KROWS_F32, EPI_SLAB>(gw, splits, 16);
         }
         CK(hipDeviceSynchronize());
         std::vector<double> ref2((size_t)H1 * H2, 0.0);
@@ -151,55 +140,41 @@ int main(int argc, char** argv)
             return out;
         };
         double m2 = 0; for (double v : ref2) m2 = std::fmax(m2, std::fabs(v));
-        std::printf("dw2    (max |value| %.1f) max |err| vs f64: f32 kernel %.3e   bf16x3 kernel %.3e   wide %.3e\n", m2, maxerr(fold(slab), ref2), maxerr(fold(slabx), ref2), maxerr(fold(slabw), ref2));
+        std::printf("dw2    (max |value| %.1f) max |err| vs f64: f32 kernel %.3e   bf16x3 kernel %.3e\n", m2, maxerr(fold(slab), ref2), maxerr(fold(slabw), ref2));
     }
     if (big > 0) {  // ---- timing at `big` rows ----
         const size_t R = (size_t)big;
-        float *h1 = dev<float>(R * H1), *h2 = dev<float>(R * H2), *d2 = dev<float>(R * H2), *d1 = dev<float>(R * H1);
+        float *h1 = dev<float>((R + 32) * H1), *h2 = dev<float>(R * H2), *d2 = dev<float>((R + 32) * H2), *d1 = dev<float>(R * H1);
+        CK(hipMemset(h1 + R * H1, 0, 32 * H1 * sizeof(float))); CK(hipMemset(d2 + R * H2, 0, 32 * H2 * sizeof(float)));
         auto hw = rnd((size_t)H1 * H2, 0.5f, 5);
         float *w2 = upload(hw), *bias = upload(rnd(H1, 0.1f, 6));
-        {   // random activations made on the device from the weights' bits would be overkill: upload in slices
+        {
             auto blk = rnd((size_t)1 << 22, 1.0f, 7);
             for (size_t off = 0; off < R * H1; off += blk.size()) CK(hipMemcpy(h1 + off, blk.data(), std::min(blk.size(), R * H1 - off) * sizeof(float), hipMemcpyHostToDevice));
             for (size_t off = 0; off < R * H2; off += blk.size()) CK(hipMemcpy(d2 + off, blk.data(), std::min(blk.size(), R * H2 - off) * sizeof(float), hipMemcpyHostToDevice));
         }
         uint32_t* w3 = split_dev(w2, (size_t)H1 * H2);
         int splits = 64; int kc = (int)((R + splits - 1) / splits); kc = (kc + 31) / 32 * 32; splits = (int)((R + kc - 1) / kc);
-        float* slab = dev<float>((size_t)splits * H1 * H2);
+        int splits_w = 128; int kcw = (int)((R + splits_w - 1) / splits_w); kcw = (kcw + 31) / 32 * 32; splits_w = (int)((R + kcw - 1) / kcw);
+        float* slab = dev<float>((size_t)splits_w * H1 * H2);
         const double flop = 2.0 * R * H1 * H2;
         GemmArgs f2{}; f2.A = h1; f2.lda = H1; f2.B = w2; f2.ldb = H2; f2.C = h2; f2.ldc = H2; f2.M = (int)R; f2.N = H2; f2.K = H1; f2.k_chunk = H1; f2.bias = bias; f2.a_vec = 1; f2.b_vec = 1;
         GemmArgs f2x = f2; f2x.B = (const float*)w3; f2x.ldb = H1; f2x.b_plane = (uint64_t)H1 * H2;
         GemmArgs dl{}; dl.A = d2; dl.lda = H2; dl.B = w2; dl.ldb = H1; dl.C = d1; dl.ldc = H1; dl.M = (int)R; dl.N = H1; dl.K = H2; dl.k_chunk = H2; dl.aux = h1; dl.ldaux = H1; dl.a_vec = 1; dl.b_vec = 1;
         GemmArgs dlx = dl; dlx.B = (const float*)w3; dlx.ldb = H2; dlx.b_plane = (uint64_t)H1 * H2;
         GemmArgs dw{}; dw.A = h1; dw.lda = H1; dw.B = d2; dw.ldb = H2; dw.C = slab; dw.ldc = H2; dw.M = H1; dw.N = H2; dw.K = (int)R; dw.k_chunk = kc; dw.a_vec = 1; dw.b_vec = 1;
+        GemmArgs dww = dw; dww.k_chunk = kcw;
         const dim3 g2(H2 / 128, (unsigned)((R + 127) / 128), 1), g1(H1 / 128, (unsigned)((R + 127) / 128), 1), gw(H2 / 128, H1 / 128, splits);
         const float t_f2 = time_us([&] { hipLaunchKernelGGL((gemm_kernel<A_ROWS, B_KROWS, EPI_BIAS_TANH, 0, 128, 32, 0>), g2, dim3(256), 0, 0, f2); }, 5);
-        const float t_f2x = time_us([&] { hipLaunchKernelGGL((gemm_x3_kernel<X3_ROWS_F32, X3_ROWS_SPLIT, EPI_BIAS_TANH, 0>), g2, dim3(256), 0, 0, f2x); }, 5);
         const float t_dl = time_us([&] { hipLaunchKernelGGL((gemm_kernel<A_ROWS, B_KROWS, EPI_MUL_DRELU, 0, 128, 32, 0>), g1, dim3(256), 0, 0, dl); }, 5);
-        const float t_dlx = time_us([&] { hipLaunchKernelGGL((gemm_x3_kernel<X3_ROWS_F32, X3_ROWS_SPLIT, EPI_MUL_DRELU, 0>), g1, dim3(256), 0, 0, dlx); }, 5);
         const float t_dw = time_us([&] { hipLaunchKernelGGL((gemm_kernel<A_KROWS, B_KROWS, EPI_SLAB, 0, 128, 32, 0>), gw, dim3(256), 0, 0, dw); }, 5);
-        const float t_dwx = time_us([&] { hipLaunchKernelGGL((gemm_x3_kernel<X3_KROWS_F32, X3_KROWS_F32, EPI_SLAB, 0>), gw, dim3(256), 0, 0, dw); }, 5);
-        int splits_w = 128; int kcw = (int)((R + splits_w - 1) / splits_w); kcw = (kcw + 31) / 32 * 32; splits_w = (int)((R + kcw - 1) / kcw);
-        float* slab_w = dev<float>((size_t)splits_w * H1 * H2);
-        GemmArgs dww = dw; dww.C = slab_w; dww.k_chunk = kcw;
-        if (std::getenv("X3_DBG")) {
-#define DBGRUN(D) { \
-            auto k1 = gemm_x3w_kernel<X3_ROWS_F32, X3_ROWS_SPLIT, EPI_BIAS_TANH, 100 * D>; auto k2 = gemm_x3w_kernel<X3_ROWS_F32, X3_ROWS_SPLIT, EPI_MUL_DRELU, 100 * D>; auto k3 = gemm_x3w_kernel<X3_KROWS_F32, X3_KROWS_F32, EPI_SLAB, 100 * D>; \
-            CK(hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)XW_LDS_BYTES)); CK(hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)XW_LDS_BYTES)); CK(hipFuncSetAttribute((const void*)k3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)XW_LDS_BYTES)); \
-            const float a = time_us([&] { hipLaunchKernelGGL(k1, dim3(H2 / 256, (unsigned)((R + 255) / 256), 1), dim3(512), XW_LDS_BYTES, 0, f2x); }, 3); \
-            const float b = time_us([&] { hipLaunchKernelGGL(k2, dim3(H1 / 256, (unsigned)((R + 255) / 256), 1), dim3(512), XW_LDS_BYTES, 0, dlx); }, 3); \
-            const float c = time_us([&] { hipLaunchKernelGGL(k3, dim3(H2 / 256, H1 / 256, splits_w), dim3(512), XW_LDS_BYTES, 0, dww); }, 3); \
-            std::printf("  wide dbg %2d: fwd2 %8.1f  delta1 %8.1f  dw2 %8.1f\n", D, a, b, c); }
-            DBGRUN(1) DBGRUN(2) DBGRUN(4) DBGRUN(8) DBGRUN(3) DBGRUN(6) DBGRUN(10) DBGRUN(14) DBGRUN(15)
-        }
+        const float t_f2w = time_us([&] { launch_w<X3_ROWS_F32, X3_ROWS_SPLIT, EPI_BIAS_TANH>(f2x, 1); }, 5);
+        const float t_dlw = time_us([&] { launch_w<X3_ROWS_F32, X3_ROWS_SPLIT, EPI_MUL_DRELU>(dlx, 1); }, 5);
+        const float t_dww = time_us([&] { launch_w<X3_KROWS_F32, X3_KROWS_F32, EPI_SLAB>(dww, splits_w); }, 5);
         std::printf("rows %zu, %d x %d   (us per launch, f32-equivalent TFLOP/s)\n", R, H1, H2);
-        const float t_f2w = time_us([&] { hipLaunchKernelGGL((gemm_x3w_kernel<X3_ROWS_F32, X3_ROWS_SPLIT, EPI_BIAS_TANH, 0>), dim3(H2 / 256, (unsigned)((R + 255) / 256), 1), dim3(512), XW_LDS_BYTES, 0, f2x); }, 5);
-        const float t_dlw = time_us([&] { hipLaunchKernelGGL((gemm_x3w_kernel<X3_ROWS_F32, X3_ROWS_SPLIT, EPI_MUL_DRELU, 0>), dim3(H1 / 256, (unsigned)((R + 255) / 256), 1), dim3(512), XW_LDS_BYTES, 0, dlx); }, 5);
-        const float t_dww = time_us([&] { hipLaunchKernelGGL((gemm_x3w_kernel<X3_KROWS_F32, X3_KROWS_F32, EPI_SLAB, 0>), dim3(H2 / 256, H1 / 256, splits_w), dim3(512), XW_LDS_BYTES, 0, dww); }, 5);
-        std::printf("  wide: fwd2 %8.1f (%.1f)  delta1 %8.1f (%.1f)  dw2 %8.1f (%.1f)\n", t_f2w, flop / t_f2w * 1e-6, t_dlw, flop / t_dlw * 1e-6, t_dww, flop / t_dww * 1e-6);
-        std::printf("  fwd2    f32 %8.1f (%.1f)   bf16x3 %8.1f (%.1f)\n", t_f2, flop / t_f2 * 1e-6, t_f2x, flop / t_f2x * 1e-6);
-        std::printf("  delta1  f32 %8.1f (%.1f)   bf16x3 %8.1f (%.1f)\n", t_dl, flop / t_dl * 1e-6, t_dlx, flop / t_dlx * 1e-6);
-        std::printf("  dw2     f32 %8.1f (%.1f)   bf16x3 %8.1f (%.1f)\n", t_dw, flop / t_dw * 1e-6, t_dwx, flop / t_dwx * 1e-6);
+        std::printf("  fwd2    f32 %8.1f (%.1f)   bf16x3 %8.1f (%.1f)\n", t_f2, flop / t_f2 * 1e-6, t_f2w, flop / t_f2w * 1e-6);
+        std::printf("  delta1  f32 %8.1f (%.1f)   bf16x3 %8.1f (%.1f)\n", t_dl, flop / t_dl * 1e-6, t_dlw, flop / t_dlw * 1e-6);
+        std::printf("  dw2     f32 %8.1f (%.1f)   bf16x3 %8.1f (%.1f)\n", t_dw, flop / t_dw * 1e-6, t_dww, flop / t_dww * 1e-6);
     }
     return 0;
 }
