@@ -30,6 +30,8 @@ import streamz_amd as sz  # noqa: E402
 
 SR = 44100
 PEAK_F32_MATRIX_TFLOPS = 157.3   # MI355X dense f32 MFMA / vector peak
+PEAK_BF16_MATRIX_TFLOPS = 2516.6  # dense bf16 MFMA: 256 CUs x 4 SIMDs x 1024 FLOP/clk x 2.4 GHz
+X3_KERNELS = ("fwd2", "delta1", "dw2")  # the products --gemm bf16x3 moves to the bf16 matrix cores, six MFMAs per term
 PEAK_HBM_GBPS = 8000.0
 
 
@@ -273,22 +275,25 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for k in range(args.warmup):
-        step(k)
-    barrier()
-    if not args.no_profile:
-        sz.profile_enable(True)
-        sz.profile_report()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(args.warmup + k, record=(k == args.steps - 1))
-    barrier()
-    elapsed = time.perf_counter() - t0
-    prof = {} if args.no_profile else sz.profile_report()
-    sz.profile_enable(False)
-    t_ext_ms = ev[0].elapsed_time(ev[1])
-    t_train_ms = ev[1].elapsed_time(ev[2])
-    loss_sum, live = [float(v) for v in grad[-2:].tolist()]
+    def timed(first_k, warmup, steps):
+        """warmup untimed steps, then `steps` timed ones between barriers; per-kernel event times of the timed ones"""
+        for k in range(warmup):
+            step(first_k + k)
+        barrier()
+        if not args.no_profile:
+            sz.profile_enable(True)
+            sz.profile_report()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            step(first_k + warmup + k, record=(k == steps - 1))
+        barrier()
+        dt = time.perf_counter() - t0
+        pr = {} if args.no_profile else sz.profile_report()
+        sz.profile_enable(False)
+        ls, lv = [float(v) for v in grad[-2:].tolist()]
+        return dt, pr, ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2]), (ls / lv if lv > 0 else None)
+
+    elapsed, prof, t_ext_ms, t_train_ms, mean_loss = timed(0, args.warmup, args.steps)
 
     if dist is not None:
         tmax = torch.tensor([elapsed], dtype=torch.float64)
@@ -317,8 +322,10 @@ def main():
             # algorithmic flops of all launches of this kernel in the timed steps / their total duration
             total_flops = flops_per_row[dom] * n_win * args.steps
             achieved = total_flops / (ms * 1e-3) / 1e12
-            roofline = {"kernel": dom, "bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MATRIX_TFLOPS,
-                        "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MATRIX_TFLOPS, "traffic": None,
+            # a split-bf16 product spends six bf16 matrix instructions per algorithmic multiply-add
+            peak = PEAK_BF16_MATRIX_TFLOPS / 6 if (args.gemm == "bf16x3" and dom in X3_KERNELS) else PEAK_F32_MATRIX_TFLOPS
+            roofline = {"kernel": dom, "bound": "mfma", "achieved": achieved, "peak": peak,
+                        "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
                         "avg_launch_us": 1000.0 * ms / cnt,
                         "launches": cnt, "flops_per_launch": total_flops / cnt,
                         "rows_per_launch": n_win * args.steps / cnt}
@@ -345,7 +352,7 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": "f32" if args.gemm == "f32" else "f32 values as three bf16 pieces each on the bf16 matrix cores, f32 accumulate",
         "data": "synthetic",
         "config": {
             "workload": (f"configs[1]: {args.clips} x {args.seconds:g} s synthetic 44.1 kHz mono clips per GPU, "
@@ -361,10 +368,25 @@ def main():
         "breakdown_ms": {"extract": t_ext_ms, "train_epoch": t_train_ms},
         "extract_windows_per_s": n_win / (t_ext_ms * 1e-3),
         "train_windows_per_s": n_win / (t_train_ms * 1e-3),
-        "mean_loss_last_step": loss_sum / live if live > 0 else None,
+        "mean_loss_last_step": mean_loss,
         "roofline": roofline,
         "kernels": kernels,
     }
+    if world == 1 and not args.no_extras and args.gemm == "f32" and H1 % 256 == 0 and H2 % 256 == 0:
+        # the same steps with the three large products on the split-bf16 kernels (opt-in; not the headline)
+        net.set_gemm("bf16x3")
+        dt, pr, te, tt, ml = timed(args.warmup + args.steps, 1, args.steps)
+        net.set_gemm("f32")
+        x3 = {"value": n_win * args.steps / dt, "unit": "windows/s", "ms_per_step": 1000.0 * dt / args.steps,
+              "breakdown_ms": {"extract": te, "train_epoch": tt}, "mean_loss_last_step": ml,
+              "arithmetic": "every f32 operand of fwd2 / delta1 / dw2 split exactly into three bf16 values; six bf16 "
+                            "MFMAs per product term (the three dropped terms are below 2^-24 relative), f32 accumulate",
+              "kernels": {t: {"avg_us": round(1000.0 * pr[t][1] / pr[t][0], 2),
+                              "TFLOPs_f32_equivalent": round(flops_per_row[t] * n_win * args.steps / (pr[t][1] * 1e-3) / 1e12, 1),
+                              "frac_of_bf16_peak_over_6": flops_per_row[t] * n_win * args.steps / (pr[t][1] * 1e-3) / 1e12
+                                                          / (PEAK_BF16_MATRIX_TFLOPS / 6)}
+                          for t in X3_KERNELS if t in pr}}
+        out["bf16x3_variant"] = x3
     if world == 1 and not args.no_extras:
         out["other_figures"] = other_figures(sz, ext, plan, pcm, feats, (60, H1, H2, C), n_win, dev, args.lr, args.dropout)
     if world == 1 and not args.no_cpu_baseline:

@@ -254,3 +254,96 @@ def augment(samples, gain, shift, noise):
 
 def seed(s):
     lib().so_seed(int(s))
+
+
+# ---- speaker-embedding bookkeeping (host-side arithmetic of the reference, numpy f32) ----------
+def _fsum(x):
+    """f32 sum in index order, like Rust's iter().sum::<f32>()"""
+    x = np.asarray(x, np.float32)
+    return np.float32(np.cumsum(x, dtype=np.float32)[-1]) if x.size else np.float32(0.0)
+
+
+def normalize(v):
+    """normalize, lib.rs:132-139: unit L2 norm unless the norm is <= 1e-6"""
+    v = np.array(v, np.float32)
+    norm = np.sqrt(_fsum(v * v))
+    return v / norm if norm > np.float32(1e-6) else v
+
+
+def average_vectors(vectors):
+    """average_vectors, lib.rs:144-159: element-wise mean, then normalize; [] for no vectors"""
+    if len(vectors) == 0:
+        return np.zeros(0, np.float32)
+    acc = np.zeros(len(vectors[0]), np.float32)
+    for v in vectors:
+        acc = acc + np.asarray(v, np.float32)
+    return normalize(acc / np.float32(len(vectors)))
+
+
+def cosine_similarity(a, b):
+    """cosine_similarity, lib.rs:1532-1541 (0.0 when either norm is 0)"""
+    a, b = np.asarray(a, np.float32), np.asarray(b, np.float32)
+    n = min(a.size, b.size)
+    dot = _fsum(a[:n] * b[:n])
+    na, nb = np.sqrt(_fsum(a * a)), np.sqrt(_fsum(b * b))
+    return np.float32(0.0) if na == 0 or nb == 0 else np.float32(dot / (na * nb))
+
+
+def identify_speaker_from_embedding(emb, speaker_embeddings, threshold):
+    """identify_speaker_from_embedding, lib.rs:1499-1529: id of the most similar centroid if its
+    similarity exceeds the threshold (x 0.7 while fewer than 20 speakers are known), else None
+    (the reference's usize::MAX).  speaker_embeddings: {id: centroid}; ids are visited in
+    ascending order (the reference's HashMap order is unspecified; it only matters on exact ties)."""
+    best_sim, best_id = np.float32(-3.4028235e38), None
+    for sid in sorted(speaker_embeddings):
+        sim = cosine_similarity(emb, speaker_embeddings[sid])
+        if sim > best_sim:
+            best_sim, best_id = sim, sid
+    dyn = np.float32(threshold) * np.float32(0.7) if len(speaker_embeddings) < 20 else np.float32(threshold)
+    return best_id if best_sim > dyn else None
+
+
+def extract_embedding_from_features(net, feats):
+    """extract_embedding_from_features, lib.rs:1450-1471: mean of forward_embedding over the windows, unit norm"""
+    feats = np.asarray(feats, np.float32).reshape(-1, 60)
+    e = net.forward_embedding(feats)
+    acc = np.zeros(e.shape[1], np.float32)
+    for row in e:
+        acc = acc + row
+    if len(e):
+        acc = acc / np.float32(len(e))
+    return normalize(acc)
+
+
+def median_embedding_from_features(net, feats):
+    """median_embedding_from_features, lib.rs:1474-1495: per-dimension median (mean of the two middle
+    values for an even count) of forward_embedding, unit norm; zeros for no windows"""
+    feats = np.asarray(feats, np.float32).reshape(-1, 60)
+    if len(feats) == 0:
+        return np.zeros(getattr(net, "h2", 0), np.float32)
+    e = np.sort(net.forward_embedding(feats), axis=0)
+    mid = len(e) // 2
+    med = (e[mid - 1] + e[mid]) / np.float32(2.0) if len(e) % 2 == 0 else e[mid]
+    return normalize(med.astype(np.float32))
+
+
+def compute_speaker_embeddings(net, feats_per_speaker, embedding_size):
+    """compute_speaker_embeddings, lib.rs:1555-1599, with the cached features of every speaker's
+    files handed in (feats_per_speaker[s] = list of (n, 60) arrays): per speaker (mean embedding,
+    mean similarity to it, standard deviation of the similarities); zeros for a speaker without files."""
+    out = []
+    for files in feats_per_speaker:
+        embeds = [median_embedding_from_features(net, f) for f in files]
+        if not embeds:
+            out.append((np.zeros(embedding_size, np.float32), np.float32(0.0), np.float32(0.0)))
+            continue
+        mean = np.zeros(embedding_size, np.float32)
+        for e in embeds:
+            mean = mean + e
+        mean = normalize(mean / np.float32(len(embeds)))
+        sims = np.array([cosine_similarity(e, mean) for e in embeds], np.float32)
+        mean_sim = _fsum(sims) / np.float32(len(sims))
+        var = _fsum((sims - mean_sim) * (sims - mean_sim)) / np.float32(len(sims))
+        out.append((mean, np.float32(mean_sim), np.float32(np.sqrt(var))))
+    return out
+

@@ -130,6 +130,15 @@ int find_arg(int argc, char** argv, const char* name)
     return -1;
 }
 
+// recompute_embeddings, main.rs:216-241: every speaker's centroid again from the embeddings collected
+// for it so far.  (The second pass already refreshes a speaker's centroid after each of its files,
+// so this leaves the map as it is; it is kept because the reference calls it.)
+void recompute_embeddings(const std::map<size_t, std::vector<std::vector<float>>>& speaker_features,
+                          std::map<size_t, std::vector<float>>& speaker_embeddings)
+{
+    for (const auto& kv : speaker_features) speaker_embeddings[kv.first] = average_vectors(kv.second);
+}
+
 // print_embedding_quality, main.rs:243-279
 void print_embedding_quality(const SimpleNeuralNet& net, const FeatureExtractor& ext)
 {
@@ -363,6 +372,7 @@ int main(int argc, char** argv)
             speaker_features[speaker_id].push_back(emb);
             speaker_embeddings[speaker_id] = average_vectors(speaker_features[speaker_id]);
             loss_count += 1;
+            if (loss_count % 100 == 0) recompute_embeddings(speaker_features, speaker_embeddings);  // main.rs:826-829
         }
 
         // main.rs:845-891

@@ -229,3 +229,70 @@ def test_cli_unlabelled_list_discovers_speakers(sz, tmp_path):
     assert len(rows) == 4 and all("," in row for row in rows)  # every file ends up labelled
     z = np.load(tmp_path / "model.npz")
     assert int(z["num_speakers"][0]) >= 2
+
+
+def test_cli_second_pass_matches_a_replay_with_the_oracle_decisions(sz, tmp_path):
+    """The labelling pass of the host binary (main.rs:710-835) on six unlabelled clips, replayed step
+    by step: the embedding bookkeeping and the matching decision come from the oracle's restatement
+    (identify_speaker_from_embedding, average_vectors, compute_speaker_embeddings; lib.rs:144-159,
+    1499-1599), the training calls from the library with the seeds the binary derives.  The labels
+    written to train_files.txt and the saved parameters must agree."""
+    from oracle import pyoracle as po
+    seed, burn = 5, 2
+    os.makedirs(tmp_path / "wav")
+    speakers = [0, 1, 0, 1, 2, 2]
+    paths, clips = [], []
+    for i, spk in enumerate(speakers):
+        pcm = synth(spk, 70 + i, seconds=2.0)
+        write_wav(str(tmp_path / "wav" / f"p{i}.wav"), pcm)
+        paths.append(f"wav/p{i}.wav")
+        clips.append(pcm)
+    (tmp_path / "train_files.txt").write_text("".join(p + "\n" for p in paths))
+    r = subprocess.run([CLI, "--seed", str(seed), "--burn-in-limit", str(burn)], cwd=tmp_path, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stderr
+    rows = [row.split(",") for row in (tmp_path / "train_files.txt").read_text().splitlines()]
+    assert [row[0] for row in rows] == paths
+    cli_labels = [int(row[1]) for row in rows]
+
+    # ---- the replay
+    ext = sz.FeatureExtractor()
+    fmap = {p: ext.extract(c) for p, c in zip(paths, clips)}
+    labels = [0] + [None] * 5                                    # no labelled file: the first one becomes speaker 0 (main.rs:640-646)
+    net = sz.SimpleNeuralNet(60, 512, 256, 1, seed=seed)
+    sz.train_from_feature_map(net, fmap, [(paths[0], 0)], 100, 0.01, 0.2, 8, seed=seed)   # main.rs:652-669
+    cents = {}
+    for i, (mean, _, _) in enumerate(po.compute_speaker_embeddings(net, [[fmap[p] for p in files] for files in net.file_lists()], 256)):
+        cents[i] = mean                                           # main.rs:714-733
+    feats_by_speaker = {}
+    count = 0
+    for i, p in enumerate(paths):
+        emb = po.normalize(sz.extract_embedding_from_features(net, fmap[p]))
+        burn_phase = count < burn
+        threshold = 0.5 if burn_phase else 0.8                    # main.rs:768-773
+        if burn_phase and labels[i] is None:
+            spk = net.output_size()
+            net.add_output_class(seed=seed + 7919 * (count + 1))
+            net.record_training_file(spk, p)
+        elif labels[i] is not None:
+            spk = labels[i]
+        else:
+            spk = po.identify_speaker_from_embedding(emb, cents, threshold)
+            if spk is None or spk >= net.output_size():           # usize::MAX: a new speaker (main.rs:793-797)
+                net.add_output_class(seed=seed + 7919 * (count + 1))
+                spk = net.output_size() - 1
+        labels[i] = spk
+        lr = 0.05 if count < 1000 else 0.01
+        sz.pretrain_from_features(net, fmap[p], spk, net.output_size(), 5, lr, 0.2, 8, seed=seed + 104729 * (count + 1))
+        net.record_training_file(spk, p)
+        feats_by_speaker.setdefault(spk, []).append(emb)
+        cents[spk] = po.average_vectors(feats_by_speaker[spk])   # main.rs:816-823
+        count += 1
+    assert cli_labels == labels
+    assert len(set(labels)) >= 2                                  # the burn-in phase alone opens a second speaker
+    z = np.load(tmp_path / "model.npz")
+    assert int(z["num_speakers"][0]) == net.output_size()
+    np.testing.assert_allclose(sz.SimpleNeuralNet.load(str(tmp_path / "model.npz")).get_flat(), net.get_flat(), atol=1e-6)
+    # the saved centroids are compute_speaker_embeddings of the final model (main.rs:845-869)
+    want = po.compute_speaker_embeddings(net, [[fmap[p] for p in files] for files in net.file_lists()], 256)
+    np.testing.assert_allclose(z["speaker_embeddings"], np.stack([m for m, _, _ in want]), atol=2e-5)
