@@ -300,6 +300,17 @@ int szh_comm_world(const szh_comm *comm);
 int szh_net_allreduce_grad_dev(szh_net *net, szh_comm *comm, void *stream);
 /* The parameters of rank `root` replace those of every other rank (start of a sharded run). */
 int szh_net_broadcast_params_dev(szh_net *net, szh_comm *comm, int root, void *stream);
+/* Epoch-synchronous data-parallel training of one rank's shard (the schedule of the task's multi-GPU
+ * configurations: files sharded over the ranks, one all-reduce of the weight gradients per epoch).
+ * feats[n][60] and labels[n] are this rank's windows in host memory (n may be 0).  Per epoch, on every
+ * rank: zero_grad, accumulate over the shard (dropout keyed by (seed + epoch, row); all-zero rows do not
+ * count, lib.rs:607-609), all-reduce over comm (NULL or a one-rank comm: none), apply with lr.
+ * *mean_loss = mean cross-entropy over all ranks' live rows in the last epoch.  Every rank must make
+ * the same call with the same epochs / lr / dropout / seed and a net holding the same parameters.
+ * Unlike train_from_feature_map (lib.rs:632-665), which steps through the files one after the other in
+ * batches of 8, this takes one optimiser step per epoch over all windows. */
+int szh_net_train_epochs_sharded(szh_net *net, szh_comm *comm, const float *feats, const int32_t *labels, uint64_t n,
+                                 uint32_t epochs, float lr, float dropout, uint64_t seed, float *mean_loss);
 
 /* ---- model metadata and persistence -------------------------------------------------- */
 

@@ -79,6 +79,8 @@ _SIGS = {
                                              C.POINTER(C.c_uint32), C.c_void_p]),
     "szh_net_grad_len": (C.c_uint64, [C.c_void_p]),
     "szh_net_grad_dev": (C.c_void_p, [C.c_void_p]),
+    "szh_net_train_epochs_sharded": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32,
+                                               C.c_float, C.c_float, C.c_uint64, C.c_void_p]),
     "szh_net_set_gemm": (C.c_int, [C.c_void_p, C.c_int]),
     "szh_net_get_gemm": (C.c_int, [C.c_void_p]),
     "szh_net_zero_grad_dev": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -349,6 +351,16 @@ class SimpleNeuralNet:
 
     def grad_ptr(self):
         return int(lib().szh_net_grad_dev(self._h))
+
+    def train_epochs_sharded(self, feats, labels, epochs, lr, dropout=0.0, seed=0, comm=None):
+        """One optimiser step per epoch over this rank's windows, gradients summed over comm's ranks
+        (szh_net_train_epochs_sharded); returns the last epoch's mean loss over all ranks."""
+        f = np.ascontiguousarray(feats, np.float32).reshape(-1, FEATURE_SIZE)
+        lab = np.ascontiguousarray(labels, np.int32)
+        loss = C.c_float()
+        _check(lib().szh_net_train_epochs_sharded(self._h, comm._h if comm is not None else None, _p(f), _p(lab), f.shape[0],
+                                                  epochs, lr, dropout, seed, C.byref(loss)))
+        return loss.value
 
     def set_gemm(self, mode):
         """"f32" or "bf16x3": arithmetic of the large batched products (SZH_GEMM_*)"""

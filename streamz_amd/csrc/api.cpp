@@ -1006,6 +1006,43 @@ int szh_net_accumulate_dev(szh_net* net, const float* feats_dev, const int32_t* 
     return net_accumulate(reinterpret_cast<Net*>(net), a, static_cast<hipStream_t>(stream));
     SZ_CATCH
 }
+int szh_net_train_epochs_sharded(szh_net* net, szh_comm* comm, const float* feats, const int32_t* labels, uint64_t n,
+                                 uint32_t epochs, float lr, float dropout, uint64_t seed, float* mean_loss)
+{
+    SZ_TRY
+    if (!net || (n && (!feats || !labels))) { set_error("null argument"); return SZH_EINVAL; }
+    Net* nn = reinterpret_cast<Net*>(net);
+    if (int rc = check_device(nn->device)) return rc;
+    std::lock_guard<std::mutex> lock(nn->mu);
+    DevBuf d_x, d_l;
+    if (int rc = d_x.alloc(n * kFeat * sizeof(float))) return rc;
+    if (int rc = d_l.alloc(n * sizeof(int32_t))) return rc;
+    if (n) {
+        SZ_HIP(hipMemcpy(d_x.p, feats, n * kFeat * sizeof(float), hipMemcpyHostToDevice));
+        SZ_HIP(hipMemcpy(d_l.p, labels, n * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
+    hipStream_t s = nullptr;
+    float tail[2] = {0.0f, 0.0f};
+    for (uint32_t ep = 0; ep < epochs; ++ep) {
+        if (int rc = net_zero_grad(nn, s)) return rc;
+        AccumArgs a;
+        a.x_dev = d_x.as<float>();
+        a.rows = n;
+        a.labels_dev = d_l.as<int32_t>();
+        a.dropout = dropout;
+        a.seed = seed + ep;
+        a.skip_zero_rows = true;
+        if (int rc = net_accumulate(nn, a, s)) return rc;
+        if (comm)
+            if (int rc = szh_net_allreduce_grad_dev(net, comm, s)) return rc;
+        if (ep + 1 == epochs) SZ_HIP(hipMemcpyAsync(tail, nn->d_grad + nn->param_count(), sizeof(tail), hipMemcpyDeviceToHost, s));
+        if (int rc = net_apply(nn, lr, s)) return rc;
+    }
+    SZ_HIP(hipStreamSynchronize(s));
+    if (mean_loss) *mean_loss = tail[1] > 0.0f ? tail[0] / tail[1] : 0.0f;
+    return SZH_OK;
+    SZ_CATCH
+}
 int szh_net_apply_grad_dev(szh_net* net, float lr, void* stream)
 {
     if (!net) { set_error("null argument"); return SZH_EINVAL; }

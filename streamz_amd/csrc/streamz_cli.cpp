@@ -10,6 +10,11 @@
 //
 //   --eval           scores target_files.txt against the embeddings saved in model.npz
 //                    (main.rs:522-625); nothing is trained or written
+//   --gpus N         (no counterpart in the reference) the initial training pass runs on N GPUs, one
+//                    process each: the labelled files are sharded over the ranks and every epoch is one
+//                    optimiser step over all windows with one RCCL all-reduce of the gradients
+//                    (szh_net_train_epochs_sharded) instead of the per-file batches of 8 of
+//                    train_from_feature_map.  The labelling pass then runs on the first GPU.
 //
 // Not handled here (outside the accelerated path): MP3 input and cache/*.wav,
 // --encode / --decode / --checksum.  The reference processes the second pass under a
@@ -27,6 +32,8 @@
 #include <vector>
 
 #include <sys/stat.h>
+#include <sys/wait.h>
+#include <unistd.h>
 
 #include "streamz.hpp"
 
@@ -217,6 +224,40 @@ int run_eval(const std::vector<Entry>& train_files, const std::vector<Entry>& ta
     return 0;
 }
 
+// The initial pass on `world` ranks (this process is `rank`; ranks > 0 are forked children that end
+// here).  id_fd: where a child reads the communicator id; id_out: where rank 0 writes it.
+float sharded_initial_pass(SimpleNeuralNet& net, const std::vector<std::pair<std::string, size_t>>& refs,
+                           const std::map<std::string, Features>& feature_map, int rank, int world, int id_fd,
+                           const std::vector<int>& id_out, uint64_t seed)
+{
+    uint8_t id[SZH_COMM_ID_BYTES];
+    if (rank == 0) {
+        check(szh_comm_unique_id(id));
+        for (int fd : id_out)
+            if (::write(fd, id, sizeof(id)) != (ssize_t)sizeof(id)) throw Error(SZH_EINVAL, "could not hand the communicator id to a rank");
+    } else if (::read(id_fd, id, sizeof(id)) != (ssize_t)sizeof(id)) {
+        throw Error(SZH_EINVAL, "no communicator id from rank 0");
+    }
+    szh_comm* comm = nullptr;
+    check(szh_comm_create(id, rank, world, &comm));
+    check(szh_net_broadcast_params_dev(net.handle(), comm, 0, nullptr));
+    // contiguous runs of the labelled files, in list order
+    const size_t lo = refs.size() * (size_t)rank / (size_t)world, hi = refs.size() * (size_t)(rank + 1) / (size_t)world;
+    std::vector<float> x;
+    std::vector<int32_t> labels;
+    for (size_t f = lo; f < hi; ++f) {
+        auto it = feature_map.find(refs[f].first);
+        if (it == feature_map.end()) continue;
+        x.insert(x.end(), it->second.data.begin(), it->second.data.end());
+        labels.insert(labels.end(), it->second.len(), (int32_t)refs[f].second);
+    }
+    float loss = 0.0f;
+    check(szh_net_train_epochs_sharded(net.handle(), comm, x.data(), labels.data(), labels.size(), (uint32_t)TRAIN_EPOCHS, 0.01f,
+                                       DROPOUT_PROB, seed, &loss));
+    szh_comm_destroy(comm);
+    return loss;
+}
+
 }  // namespace
 
 int main(int argc, char** argv)
@@ -228,8 +269,34 @@ int main(int argc, char** argv)
         int idx;
         uint64_t seed = 0x5EEDull;
         if ((idx = find_arg(argc, argv, "--seed")) >= 0 && idx + 1 < argc) seed = std::strtoull(argv[idx + 1], nullptr, 10);
-        if ((idx = find_arg(argc, argv, "--device")) >= 0 && idx + 1 < argc) check(szh_init(std::atoi(argv[idx + 1])));
         const bool eval_mode = find_arg(argc, argv, "--eval") >= 0;  // main.rs:350
+        // --gpus N: the ranks are separate processes, forked before anything touches a GPU
+        int world = 1, rank = 0, id_fd = -1;
+        std::vector<int> id_out;
+        std::vector<pid_t> children;
+        bool sharded = false;  // --gpus given (1 is allowed: the same schedule on one rank)
+        if ((idx = find_arg(argc, argv, "--gpus")) >= 0 && idx + 1 < argc) { world = std::max(1, std::atoi(argv[idx + 1])); sharded = true; }
+        if (sharded && (eval_mode || exists(MODEL_PATH))) {
+            std::fprintf(stderr, "--gpus only spreads the initial training pass, which this run does not make; using one GPU\n");
+            world = 1;
+            sharded = false;
+        }
+        for (int r = 1; r < world && rank == 0; ++r) {
+            int fd[2];
+            if (::pipe(fd) != 0) throw Error(SZH_EINVAL, "pipe failed");
+            std::fflush(stdout);
+            const pid_t pid = ::fork();
+            if (pid < 0) throw Error(SZH_EINVAL, "fork failed");
+            if (pid == 0) {
+                rank = r; id_fd = fd[0]; ::close(fd[1]);
+                for (int w : id_out) ::close(w);
+                id_out.clear(); children.clear();
+            } else {
+                ::close(fd[0]); id_out.push_back(fd[1]); children.push_back(pid);
+            }
+        }
+        if (sharded) check(szh_init(rank));
+        else if ((idx = find_arg(argc, argv, "--device")) >= 0 && idx + 1 < argc) check(szh_init(std::atoi(argv[idx + 1])));
         for (const char* flag : {"--encode", "--decode", "--checksum"})
             if (find_arg(argc, argv, flag) >= 0) {
                 std::fprintf(stderr, "%s is not part of the accelerated path and is not handled by this binary\n", flag);
@@ -320,7 +387,17 @@ int main(int argc, char** argv)
             std::vector<std::pair<std::string, size_t>> refs;
             for (const Entry& e : train_files)
                 if (e.labelled) refs.emplace_back(e.path, e.cls);
-            if (!refs.empty()) {
+            if (sharded) {
+                const float loss = sharded_initial_pass(net, refs, feature_map, rank, world, id_fd, id_out, seed);
+                if (rank != 0) { std::fflush(nullptr); ::_exit(0); }  // a rank's part ends with the initial pass
+                for (int fd : id_out) ::close(fd);
+                for (pid_t pid : children) {
+                    int status = 0;
+                    if (::waitpid(pid, &status, 0) < 0 || !WIFEXITED(status) || WEXITSTATUS(status) != 0)
+                        throw Error(SZH_EINVAL, "a rank of the initial pass failed");
+                }
+                std::printf("Initial training loss: %.4f  (%d GPU%s, one optimiser step per epoch)\n", loss, world, world > 1 ? "s" : "");
+            } else if (!refs.empty()) {
                 const float loss = train_from_feature_map(net, feature_map, refs, TRAIN_EPOCHS, 0.01f, DROPOUT_PROB, BATCH_SIZE, seed);
                 std::printf("Initial training loss: %.4f\n", loss);
             }

@@ -296,3 +296,33 @@ def test_cli_second_pass_matches_a_replay_with_the_oracle_decisions(sz, tmp_path
     # the saved centroids are compute_speaker_embeddings of the final model (main.rs:845-869)
     want = po.compute_speaker_embeddings(net, [[fmap[p] for p in files] for files in net.file_lists()], 256)
     np.testing.assert_allclose(z["speaker_embeddings"], np.stack([m for m, _, _ in want]), atol=2e-5)
+
+
+def test_cli_gpus_option_runs_the_epoch_synchronous_initial_pass(sz, tmp_path):
+    """--gpus 1: the initial pass as one optimiser step per epoch over all windows, through the
+    library's RCCL communicator (one rank here; more ranks are forked the same way, one per GPU).
+    The printed loss is that of szh_net_train_epochs_sharded on the same windows."""
+    import re
+    os.makedirs(tmp_path / "wav")
+    clips, lines = [], []
+    for i in range(6):
+        pcm = synth(i % 2, 90 + i, seconds=2.0)
+        write_wav(str(tmp_path / "wav" / f"g{i}.wav"), pcm)
+        clips.append(pcm)
+        lines.append(f"wav/g{i}.wav,{i % 2}")
+    (tmp_path / "train_files.txt").write_text("\n".join(lines) + "\n")
+    r = subprocess.run([CLI, "--seed", "21", "--gpus", "1"], cwd=tmp_path, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr
+    m = re.search(r"Initial training loss: ([0-9.]+)  \(1 GPU, one optimiser step per epoch\)", r.stdout)
+    assert m, r.stdout
+    ext = sz.FeatureExtractor()
+    feats = [ext.extract(c) for c in clips]
+    net = sz.SimpleNeuralNet(60, 512, 256, 2, seed=21)
+    loss = net.train_epochs_sharded(np.concatenate(feats), np.concatenate([np.full(len(f), i % 2, np.int32) for i, f in enumerate(feats)]),
+                                    100, 0.01, dropout=0.2, seed=21)
+    assert abs(float(m.group(1)) - loss) < 1e-4
+    assert (tmp_path / "train_files.txt").read_text().splitlines() == lines
+    assert int(np.load(tmp_path / "model.npz")["num_speakers"][0]) == 2
+    # a saved model means no initial pass: the option is refused with a note, the run goes on
+    r2 = subprocess.run([CLI, "--seed", "21", "--gpus", "2"], cwd=tmp_path, capture_output=True, text=True, timeout=900)
+    assert r2.returncode == 0 and "using one GPU" in r2.stderr

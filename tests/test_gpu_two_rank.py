@@ -168,3 +168,52 @@ def test_bench_multi_rank_branch():
                        MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0"))
     assert "RCCL" in rccl["config"]["batch"]
     assert rccl["mean_loss_last_step"] == one["mean_loss_last_step"]
+
+
+def test_train_epochs_sharded_is_the_device_epoch_loop_and_matches_the_oracle():
+    """szh_net_train_epochs_sharded on one rank (no communicator, and a one-rank RCCL communicator):
+    bit for bit the zero_grad / accumulate_dev / apply_grad_dev loop, and the oracle's full-batch
+    epochs within tolerance (body of lib.rs:1013-1059 over all rows, one update per epoch)."""
+    import torch
+    import streamz_amd as sz
+    from oracle import pyoracle as po
+    from helpers import grad_view
+    dims, epochs, lr = (60, 512, 256, 4), 3, 0.05
+    rng = np.random.default_rng(5)
+    onet = po.Net(*dims)
+    params = [rng.uniform(-0.5, 0.5, s).astype(np.float32) for s in onet.shapes()]
+    x = rng.standard_normal((1500, 60)).astype(np.float32)
+    x[7] = 0.0
+    labels = rng.integers(0, 4, len(x)).astype(np.int32)
+    a = sz.SimpleNeuralNet(*dims, init=params)
+    loss_a = a.train_epochs_sharded(x, labels, epochs, lr, dropout=0.2, seed=77)
+    # the same steps through the device entry points
+    b = sz.SimpleNeuralNet(*dims, init=params)
+    dx, dl = torch.from_numpy(x).cuda(), torch.from_numpy(labels).cuda()
+    for ep in range(epochs):
+        b.zero_grad_dev(0)
+        b.accumulate_dev(dx.data_ptr(), dl.data_ptr(), len(x), 0.2, 77 + ep, 0)
+        torch.cuda.synchronize()
+        tail = grad_view(b)[-2:].cpu().numpy()
+        b.apply_grad_dev(lr, 0)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(a.get_flat(), b.get_flat())
+    assert loss_a == np.float32(tail[0]) / np.float32(tail[1])
+    # a communicator of one rank: the all-reduce leaves the sums as they are
+    c = sz.SimpleNeuralNet(*dims, init=params)
+    comm = sz.Comm(sz.comm_unique_id(), 0, 1)
+    loss_c = c.train_epochs_sharded(x, labels, epochs, lr, dropout=0.2, seed=77, comm=comm)
+    np.testing.assert_array_equal(c.get_flat(), a.get_flat())
+    assert loss_c == loss_a
+    # without dropout against the oracle
+    d = sz.SimpleNeuralNet(*dims, init=params)
+    loss_d = d.train_epochs_sharded(x, labels, epochs, lr)
+    onet.set_params(params)
+    live = np.any(x != 0.0, axis=1)
+    for ep in range(epochs):
+        probs = onet.forward(x[live])
+        oloss = -np.log(np.maximum(probs[np.arange(live.sum()), labels[live]], 1e-12)).mean()
+        onet.apply(onet.grad(x[live], labels=labels[live]), lr / live.sum())
+    want = np.concatenate([p.ravel() for p in onet.get_params()])
+    np.testing.assert_allclose(d.get_flat(), want, atol=2e-5)
+    assert abs(loss_d - oloss) < 1e-4 * max(1.0, oloss)
