@@ -122,12 +122,12 @@ def cpu_baseline(speakers, hidden, seconds):
     }
 
 
-def measured_traffic(kernel, rows_per_launch):
-    """HBM bytes per launch of `kernel` from the newest committed FETCH_SIZE / WRITE_SIZE passes
-    (profiles/*_pmc_traffic.json: separate rocprofv3 --pmc runs of tools/net_bench on the same
-    kernels and row counts, FETCH_SIZE doubled as gfx950 requires), or None."""
+def measured_traffic(kernel, rows_per_launch, gemm="f32"):
+    """HBM bytes per launch of `kernel` from the newest committed FETCH_SIZE / WRITE_SIZE passes of the
+    same GEMM mode (profiles/*_<mode>_pmc_traffic.json: separate rocprofv3 --pmc runs of
+    tools/net_bench on the same kernels and row counts, FETCH_SIZE doubled as gfx950 requires), or None."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_{gemm}_pmc_traffic.json")))
     if not files:
         return None, None
     with open(files[-1]) as f:
@@ -329,7 +329,7 @@ def main():
                         "avg_launch_us": 1000.0 * ms / cnt,
                         "launches": cnt, "flops_per_launch": total_flops / cnt,
                         "rows_per_launch": n_win * args.steps / cnt}
-            roofline["traffic"], roofline["traffic_source"] = measured_traffic(dom, n_win * args.steps / cnt)
+            roofline["traffic"], roofline["traffic_source"] = measured_traffic(dom, n_win * args.steps / cnt, args.gemm)
         else:
             total_bytes = 1040.0 * n_win * args.steps
             achieved = total_bytes / (ms * 1e-3) / 1e9

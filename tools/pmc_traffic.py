@@ -12,11 +12,11 @@ import sys
 
 GEMM_TAGS = ["fwd1", "fwd2", "fwd3", "delta2", "delta1", "dw3", "dw2", "dw1"]
 OTHER = {"prep_rows_kernel": "prep", "head_mfma_kernel": "head", "head_wide_kernel": "head", "head_kernel": "head",
-         "slab_reduce_kernel": "reduce", "transpose_kernel": "w2t", "apply_kernel": "apply"}
+         "slab_reduce_kernel": "reduce", "transpose_kernel": "w2t", "apply_kernel": "apply", "split_planes_kernel": "w2split"}
 
 
 def tag_of(name):
-    m = re.search(r"gemm_kernel<\d+, \d+, \d+, (\d+),", name)
+    m = re.search(r"gemm_kernel<\d+, \d+, \d+, (\d+),", name) or re.search(r"gemm_x3w_kernel<\d+, \d+, \d+, (\d+)>", name)
     if m:
         return GEMM_TAGS[int(m.group(1))]
     for key, tag in OTHER.items():
