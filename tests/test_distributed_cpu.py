@@ -1,8 +1,10 @@
 """The N>1 training step on CPU (gloo, world size 2): every rank sums gradients over its own
 shard of files, the [gradient | loss | live rows] vector is all-reduced, every rank applies
 lr / global_live_rows.  The compute on each rank is the CPU oracle (no GPU here); the result
-must equal one process doing the same step over all files.  This is the protocol bench.py
-and the szh_net_*_dev entry points implement on the GPU with RCCL."""
+must equal one process doing the same step over all files.  It checks the sharding arithmetic and
+the sum-then-update algebra of that protocol only: no product code runs here.  The product's own
+path (szh_net_*_dev, the library's RCCL communicator, bench.py's multi-rank branch) is exercised by
+tests/test_gpu_two_rank.py on a GPU."""
 import os
 import socket
 
