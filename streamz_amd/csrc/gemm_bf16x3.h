@@ -193,7 +193,7 @@ __global__ __launch_bounds__(XW_THREADS) void gemm_x3w_kernel(GemmArgs g)
 
     while (true) {
         float* C = g.C;
-        if (EPI == EPI_SLAB) C += (size_t)cur.bz * (size_t)g.M * (size_t)g.ldc;
+        if (EPI == EPI_SLAB) C += (size_t)cur.bz * (g.slab_stride ? (size_t)g.slab_stride : (size_t)g.M * (size_t)g.ldc);
         f32x16 acc[2][TN];
 #pragma unroll
         for (int i = 0; i < 2; ++i)

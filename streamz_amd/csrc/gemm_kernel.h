@@ -56,6 +56,7 @@ struct GemmArgs {
                                // column and block of 32 rows (what one lane of an MFMA tile holds)
     uint64_t b_plane = 0;      // split-bf16 kernel: elements between the three planes of a pre-split B
     int tiles_x = 0, tiles_y = 0, tiles_z = 0;  // split-bf16 kernel: tiles along N, M and the K ranges
+    uint64_t slab_stride = 0;  // split-bf16 kernel, EPI_SLAB: floats between the slabs of two K ranges (0: M * ldc)
 };
 
 struct Frag4 { float v[4]; };

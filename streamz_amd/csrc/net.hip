@@ -89,6 +89,9 @@ inline bool use_x3(const Net* n, uint64_t rows)
     return n->gemm_mode == SZH_GEMM_BF16X3 && n->h1 % 256 == 0 && n->h2 % 256 == 0 && rows >= 1024;
 }
 
+// ... and the output layer's products too (they run as GEMMs only beyond 64 classes)
+inline bool use_x3_out(const Net* n, uint64_t rows) { return use_x3(n, rows) && n->out % 256 == 0; }
+
 // ---- row preparation: gather by permutation, input dropout, all-zero flag -------------
 // (lib.rs:604-609: clone, apply_dropout, skip rows whose 60 values are all exactly 0.0)
 // One workgroup prepares 64 rows, one element per thread and step, so that reads and writes are
@@ -1134,7 +1137,7 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
 
 // ---- column sums (bias gradients), split over rows into slabs ------------------------
 __global__ void colsum_kernel(const float* __restrict__ D, uint64_t rows, int cols, int ld, int rows_per_split,
-                              int add, float* __restrict__ slab)
+                              int add, float* __restrict__ slab, uint64_t slab_stride)
 {
     __shared__ float part[4][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
@@ -1154,7 +1157,7 @@ __global__ void colsum_kernel(const float* __restrict__ D, uint64_t rows, int co
     part[rg][threadIdx.x & 63] = s;
     __syncthreads();
     if (rg == 0 && c < cols) {
-        float* p = slab + (size_t)blockIdx.y * cols + c;
+        float* p = slab + (size_t)blockIdx.y * slab_stride + c;
         *p = (add ? *p : 0.0f) + ((part[0][threadIdx.x] + part[1][threadIdx.x]) +
                                   (part[2][threadIdx.x] + part[3][threadIdx.x]));
     }
@@ -1275,6 +1278,8 @@ int ensure_workspace(Net* n, uint64_t rows)
     float** ptrs[] = {&w.xd, &w.h1, &w.h2, &w.p, &w.d2, &w.d1, &w.slab, &w.w2t};
     for (float** p : ptrs) { if (*p) (void)hipFree(*p); *p = nullptr; }
     if (w.w2s) { (void)hipFree(w.w2s); w.w2s = nullptr; }
+    if (w.w3s) { (void)hipFree(w.w3s); w.w3s = nullptr; }
+    if (w.w3t) { (void)hipFree(w.w3t); w.w3t = nullptr; }
     if (w.live) { (void)hipFree(w.live); w.live = nullptr; }
     if (w.mask) { (void)hipFree(w.mask); w.mask = nullptr; }
     if (w.stat_slab) { (void)hipFree(w.stat_slab); w.stat_slab = nullptr; }
@@ -1295,8 +1300,8 @@ int ensure_workspace(Net* n, uint64_t rows)
     // h1 and d2 carry 32 rows of slack: the split-bf16 weight-gradient kernel reads whole groups of
     // 32 rows and wants zeros behind the last one
     SZ_HIP(hipMalloc((void**)&w.h1, (R + 32) * n->h1 * sizeof(float)));
-    SZ_HIP(hipMalloc((void**)&w.h2, R * n->h2 * sizeof(float)));
-    SZ_HIP(hipMalloc((void**)&w.p, R * (n->out ? n->out : 1) * sizeof(float)));
+    SZ_HIP(hipMalloc((void**)&w.h2, (R + 32) * n->h2 * sizeof(float)));
+    SZ_HIP(hipMalloc((void**)&w.p, (R + 32) * (n->out ? n->out : 1) * sizeof(float)));
     SZ_HIP(hipMalloc((void**)&w.d2, (R + 32) * n->h2 * sizeof(float)));
     SZ_HIP(hipMalloc((void**)&w.d1, R * n->h1 * sizeof(float)));
     SZ_HIP(hipMalloc((void**)&w.slab, w.slab_floats * sizeof(float)));
@@ -1305,6 +1310,8 @@ int ensure_workspace(Net* n, uint64_t rows)
     SZ_HIP(hipMalloc((void**)&w.mask, ((R + 255) / 256 * 8) * (uint64_t)n->h1 * sizeof(uint32_t)));
     // w2 and its transpose as bf16 planes, [2][3][hidden1 * hidden2]
     SZ_HIP(hipMalloc((void**)&w.w2s, 2 * 3 * ((uint64_t)n->h1 * n->h2 + 1) * sizeof(uint16_t)));
+    SZ_HIP(hipMalloc((void**)&w.w3s, 2 * 3 * ((uint64_t)n->h2 * n->out + 2) * sizeof(uint16_t)));
+    SZ_HIP(hipMalloc((void**)&w.w3t, ((uint64_t)n->h2 * n->out + 1) * sizeof(float)));
     SZ_HIP(hipMalloc((void**)&w.stat_slab, 2 * head_blocks * sizeof(double)));
     SZ_HIP(hipMalloc((void**)&w.w2t, ((uint64_t)n->h1 * n->h2 + 8 * 64 * 4 * ((n->h2 + 15) / 16)) * sizeof(float)));
     w.rows = R;
@@ -1329,6 +1336,15 @@ int prepare_w2_planes(Net* n, bool backward, bool transposed_ready, hipStream_t 
     if (backward)
         hipLaunchKernelGGL(split_planes_kernel, dim3(blocks), dim3(256), 0, s, P + n->off_w2(), count, w.w2s + 3 * (count / 2),
                            count / 2);
+    if (n->out % 256 == 0 && n->out > 0) {  // the output layer as [classes][hidden2] planes, and as it is for delta2
+        const uint64_t c3 = (uint64_t)n->h2 * n->out;
+        const unsigned b3 = (unsigned)((c3 / 2 + 255) / 256);
+        hipLaunchKernelGGL(transpose_kernel, dim3((n->out + 31) / 32, (n->h2 + 31) / 32), dim3(256), 0, s,
+                           P + n->off_w3(), (int)n->h2, (int)n->out, w.w3t);
+        hipLaunchKernelGGL(split_planes_kernel, dim3(b3), dim3(256), 0, s, w.w3t, c3, w.w3s, c3 / 2);
+        if (backward)
+            hipLaunchKernelGGL(split_planes_kernel, dim3(b3), dim3(256), 0, s, P + n->off_w3(), c3, w.w3s + 3 * (c3 / 2), c3 / 2);
+    }
     SZ_HIP(hipGetLastError());
     return SZH_OK;
 }
@@ -1360,13 +1376,17 @@ int forward_hidden(Net* n, const float* x, uint64_t rows, bool relu2, hipStream_
                  : launch_gemm<A_ROWS, B_KROWS, EPI_BIAS_TANH, T_FWD2>(g, 1, s);
 }
 
-int forward_logits(Net* n, uint64_t rows, float* out, hipStream_t s)
+int forward_logits(Net* n, uint64_t rows, float* out, hipStream_t s, bool x3 = false)
 {
     Workspace& w = n->ws;
     const float* P = n->d_params;
     GemmArgs g{};
     g.A = w.h2; g.lda = n->h2; g.B = P + n->off_w3(); g.ldb = n->out; g.C = out; g.ldc = n->out;
     g.M = (int)rows; g.N = n->out; g.K = n->h2; g.k_chunk = n->h2; g.bias = P + n->off_b3();
+    if (x3) {  // B as [classes][hidden2] planes
+        g.B = (const float*)w.w3s; g.ldb = n->h2; g.b_plane = (uint64_t)n->h2 * n->out;
+        return launch_gemm_x3<X3_ROWS_F32, X3_ROWS_SPLIT, EPI_BIAS, T_FWD3>(g, 1, s);
+    }
     return launch_gemm<A_ROWS, B_KROWS, EPI_BIAS, T_FWD3>(g, 1, s);
 }
 
@@ -1403,12 +1423,13 @@ int grad_gemm(const float* A, int lda, const float* B, int ldb, int M, int N, ui
 // the same contraction on the split-bf16 kernel (M and N multiples of 256, no bias row)
 template <int TAG>
 int grad_gemm_x3(const float* A, int lda, const float* B, int ldb, int M, int N, uint64_t rows, float* slab,
-                 const SplitPlan& sp, bool add, hipStream_t s)
+                 const SplitPlan& sp, bool add, hipStream_t s, uint64_t slab_stride = 0)
 {
     GemmArgs g{};
     g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = slab; g.ldc = N;
     g.M = M; g.N = N; g.K = (int)rows; g.k_chunk = sp.k_chunk;
     g.slab_add = add ? 1 : 0;
+    g.slab_stride = slab_stride;
     return launch_gemm_x3<X3_KROWS_F32, X3_KROWS_F32, EPI_SLAB, TAG>(g, (int)((rows + sp.k_chunk - 1) / sp.k_chunk), s);
 }
 
@@ -1421,11 +1442,13 @@ int reduce_slabs(const float* slab, int splits, uint64_t len, float* grad, hipSt
     return SZH_OK;
 }
 
-int colsum_slabs(const float* D, int cols, uint64_t rows, float* slab, const SplitPlan& sp, bool add, hipStream_t s)
+// slab_stride: floats between the sums of two K ranges (0: cols)
+int colsum_slabs(const float* D, int cols, uint64_t rows, float* slab, const SplitPlan& sp, bool add, hipStream_t s,
+                 uint64_t slab_stride = 0)
 {
     ProfScope prof("bias", s);
     hipLaunchKernelGGL(colsum_kernel, dim3((cols + 63) / 64, (unsigned)((rows + sp.k_chunk - 1) / sp.k_chunk)),
-                       dim3(256), 0, s, D, rows, cols, cols, sp.k_chunk, add ? 1 : 0, slab);
+                       dim3(256), 0, s, D, rows, cols, cols, sp.k_chunk, add ? 1 : 0, slab, slab_stride ? slab_stride : (uint64_t)cols);
     SZ_HIP(hipGetLastError());
     return SZH_OK;
 }
@@ -1474,6 +1497,8 @@ void net_destroy(Net* n)
     float* ptrs[] = {w.xd, w.h1, w.h2, w.p, w.d2, w.d1, w.slab, w.w2t, n->d_params, n->d_grad};
     for (float* p : ptrs) if (p) (void)hipFree(p);
     if (w.w2s) (void)hipFree(w.w2s);
+    if (w.w3s) (void)hipFree(w.w3s);
+    if (w.w3t) (void)hipFree(w.w3t);
     if (w.live) (void)hipFree(w.live);
     if (w.mask) (void)hipFree(w.mask);
     if (w.stat_slab) (void)hipFree(w.stat_slab);
@@ -1542,7 +1567,7 @@ int net_forward_dev(Net* n, const float* x_dev, uint64_t rows, float* out_dev, F
         float* o = out_dev + r0 * ow;
         if (kind == kFwdProbs) {
             if (n->out == 0) continue;
-            rc = forward_logits(n, R, o, s);
+            rc = forward_logits(n, R, o, s, x3 && use_x3_out(n, rows));
             if (rc) return rc;
             rc = launch_softmax(o, R, (int)n->out, 0, nullptr, nullptr, nullptr, nullptr, s);
             if (rc) return rc;
@@ -1717,7 +1742,8 @@ int net_accumulate(Net* n, const AccumArgs& a, hipStream_t s)
                 if (rc) return rc;
             }
         } else {
-            rc = forward_logits(n, R, w.p, s);
+            const bool x3o = use_x3_out(n, a.rows);
+            rc = forward_logits(n, R, w.p, s, x3o);
             if (rc) return rc;
             {
                 ProfScope prof("softmax", s);
@@ -1729,10 +1755,27 @@ int net_accumulate(Net* n, const AccumArgs& a, hipStream_t s)
             GemmArgs g{};
             g.A = w.p; g.lda = n->out; g.B = P + n->off_w3(); g.ldb = n->out; g.C = w.d2; g.ldc = n->h2;
             g.M = (int)R; g.N = n->h2; g.K = n->out; g.k_chunk = n->out; g.aux = w.h2; g.ldaux = n->h2;
-            rc = launch_gemm<A_ROWS, B_ROWS, EPI_MUL_DTANH, T_DELTA2>(g, 1, s);
-            if (rc) return rc;
-            rc = grad_gemm<T_DW3>(w.h2, n->h2, w.p, n->out, n->h2, n->out, R, w.slab + w.sl_w3, sp, add, true, s);
-            if (rc) return rc;
+            if (x3o) {  // B as [hidden2][classes] planes: w3 itself
+                g.B = (const float*)(w.w3s + 3 * ((uint64_t)n->h2 * n->out / 2)); g.ldb = n->out;
+                g.b_plane = (uint64_t)n->h2 * n->out;
+                rc = launch_gemm_x3<X3_ROWS_F32, X3_ROWS_SPLIT, EPI_MUL_DTANH, T_DELTA2>(g, 1, s);
+                if (rc) return rc;
+                if (R % 32) {  // zero rows up to the next multiple of 32 for the k-major reads of dW3
+                    const uint64_t pad = 32 - R % 32;
+                    SZ_HIP(hipMemsetAsync(w.h2 + R * n->h2, 0, pad * n->h2 * sizeof(float), s));
+                    SZ_HIP(hipMemsetAsync(w.p + R * n->out, 0, pad * n->out * sizeof(float), s));
+                }
+                // [dW3 | db3] per K range: the matrix part from the GEMM, the bias row from column sums
+                rc = grad_gemm_x3<T_DW3>(w.h2, n->h2, w.p, n->out, n->h2, n->out, R, w.slab + w.sl_w3, sp, add, s, len3);
+                if (rc) return rc;
+                rc = colsum_slabs(w.p, n->out, R, w.slab + w.sl_w3 + (uint64_t)n->h2 * n->out, sp, add, s, len3);
+                if (rc) return rc;
+            } else {
+                rc = launch_gemm<A_ROWS, B_ROWS, EPI_MUL_DTANH, T_DELTA2>(g, 1, s);
+                if (rc) return rc;
+                rc = grad_gemm<T_DW3>(w.h2, n->h2, w.p, n->out, n->h2, n->out, R, w.slab + w.sl_w3, sp, add, true, s);
+                if (rc) return rc;
+            }
             rc = colsum_slabs(w.d2, n->h2, R, w.slab + w.sl_b2, sp, add, s);
             if (rc) return rc;
         }
