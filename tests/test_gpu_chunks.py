@@ -30,13 +30,12 @@ def grad_of(net):
 
 rng = np.random.default_rng(4)
 # MFMA head, VALU head, GEMM output path, MFMA head + dW3 GEMM with 2, 3 and 4 blocks of 16 classes
-for dims in ((60, 512, 256, 16), (60, 64, 32, 5), (60, 96, 40, 40), (60, 64, 128, 17), (60, 128, 64, 40), (60, 512, 256, 64),
-             (60, 160, 320, 70)):   # wider than any head kernel: GEMM output path
+for dims in %(dims)s:
     onet = po.Net(*dims)
     params = [rng.uniform(-0.5, 0.5, s).astype(np.float32) for s in onet.shapes()]
     onet.set_params(params)
     net = sz.SimpleNeuralNet(*dims, init=params)
-    n = 1000
+    n = %(n)d
     x = rng.standard_normal((n, 60)).astype(np.float32)
     x[17] = 0.0                                   # an all-zero row does not count (lib.rs:607-609)
     labels = rng.integers(0, dims[3], n).astype(np.int32)
@@ -63,9 +62,27 @@ print("chunks ok")
 """
 
 
+# MFMA head, VALU head, GEMM output path, MFMA head + dW3 GEMM with 2, 3 and 4 blocks of 16 classes,
+# and one net wider than any head kernel (GEMM output path)
+DIMS = "((60, 512, 256, 16), (60, 64, 32, 5), (60, 96, 40, 40), (60, 64, 128, 17), (60, 128, 64, 40), (60, 512, 256, 64), (60, 160, 320, 70))"
+
+
 def test_accumulate_over_small_chunks_matches_oracle():
     env = dict(os.environ, STREAMZ_CHUNK_ROWS="256")
-    r = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT}], env=env, capture_output=True, text=True,
-                       timeout=600)
+    r = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT, "dims": DIMS, "n": 1000}], env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "chunks ok" in r.stdout
+
+
+def test_split_bf16_mode_over_small_chunks_matches_oracle():
+    """The same with the split-bf16 kernels (STREAMZ_GEMM=bf16x3): 3 000 rows in eight chunks of 384 rows
+    (the last one 312 rows: not a multiple of the 32 rows the k-major reads take at a time, so the rows
+    behind it are zeroed), weight-gradient slabs adding over chunks with workgroups that walk over several
+    tiles; a 16-class net (MFMA head) and a 256-class one (output layer on the same kernels)."""
+    env = dict(os.environ, STREAMZ_CHUNK_ROWS="384", STREAMZ_GEMM="bf16x3")
+    dims = "((60, 512, 256, 16), (60, 256, 256, 256))"
+    r = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT, "dims": dims, "n": 3000}], env=env, capture_output=True,
+                       text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert "chunks ok" in r.stdout
