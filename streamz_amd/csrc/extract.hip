@@ -9,6 +9,8 @@
 //   finish_kernel     deltas with edge replication at file boundaries, concat and per-frame
 //                     z-score (lib.rs:212-228, 321-342); streams 80 B in, 240 B out per window.
 #include <algorithm>
+#include <cstring>
+#include <new>
 
 #include "extract_phases.h"
 #include "internal.h"
@@ -32,15 +34,26 @@ __device__ __forceinline__ void wave_sync()
 
 constexpr int kBaseThreads = 256;
 constexpr int kBaseWaves = kBaseThreads / 64;
-constexpr size_t kBaseLdsBytes = (size_t)kBaseWaves * kWinPerWave * kRegionStride * sizeof(float);
+constexpr size_t kRegionBytes = (size_t)kBaseWaves * kWinPerWave * kRegionStride * sizeof(float);
+// the windows' scratch regions, then the workgroup's copy of the tables
+constexpr size_t kBaseLdsBytes = kRegionBytes + sizeof(KernelTables);
+static_assert(kRegionBytes % 16 == 0 && 3 * kBaseLdsBytes <= 160 * 1024, "three workgroups per CU");
 
 __global__ __launch_bounds__(kBaseThreads, 3) void mfcc_base_kernel(const int16_t* __restrict__ pcm,
                                                                   const Segment* __restrict__ segs,
                                                                   uint32_t n_segs,
-                                                                  const ExtractTables* __restrict__ T,
+                                                                  const KernelTables* __restrict__ Tg,
                                                                   float* __restrict__ base)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    // the tables into LDS, once per workgroup (the only workgroup barrier of the kernel)
+    const KernelTables* T = reinterpret_cast<const KernelTables*>(reinterpret_cast<const char*>(lds) + kRegionBytes);
+    {
+        const float4* src = reinterpret_cast<const float4*>(Tg);
+        float4* dst = reinterpret_cast<float4*>(reinterpret_cast<char*>(lds) + kRegionBytes);
+        for (int i = threadIdx.x; i < (int)(sizeof(KernelTables) / 16); i += kBaseThreads) dst[i] = src[i];
+    }
+    __syncthreads();
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     // lanes 60..63 shadow lanes 50..53: same inputs, same LDS writes, no global store
@@ -56,9 +69,9 @@ __global__ __launch_bounds__(kBaseThreads, 3) void mfcc_base_kernel(const int16_
             const bool valid = wi < S.n_win;
             if (!valid) wi = S.n_win - 1;
             const int16_t* win = pcm + S.pcm_off + (uint64_t)wi * kHop;
-            // The tables are re-read (from L1 / the scalar cache) in every iteration: letting
-            // the compiler hoist ~250 loop-invariant twiddle loads into registers spills.
-            // (The opaque value is an offset, not the pointer, so the loads stay global_load.)
+            // The tables are re-read from LDS in every iteration: letting the compiler hoist ~250
+            // loop-invariant twiddle loads into registers spills.  (The opaque value is an offset,
+            // not the pointer, so the address space of the loads stays known.)
             uint32_t opaque0 = 0;
             asm volatile("" : "+s"(opaque0));
             {
@@ -201,8 +214,19 @@ int extractor_create(Extractor** out)
         return SZH_EINVAL;
     }
     hipError_t he = hipGetDevice(&e->device);
-    if (he == hipSuccess) he = hipMalloc((void**)&e->dev, sizeof(ExtractTables));
-    if (he == hipSuccess) he = hipMemcpy(e->dev, &e->host, sizeof(ExtractTables), hipMemcpyHostToDevice);
+    KernelTables* kt = new (std::nothrow) KernelTables();
+    if (!kt) { delete e; set_error("out of host memory"); return SZH_ENOMEM; }
+    std::memcpy(kt->twa, e->host.twa, sizeof(kt->twa));
+    std::memcpy(kt->twb, e->host.twb, sizeof(kt->twb));
+    std::memcpy(kt->sw, e->host.sw, sizeof(kt->sw));
+    std::memcpy(kt->pk, e->host.pk, sizeof(kt->pk));
+    std::memcpy(kt->melw, e->host.melw, sizeof(kt->melw));
+    std::memcpy(kt->mel_flush, e->host.mel_flush, sizeof(kt->mel_flush));
+    std::memcpy(kt->comb_pos, e->host.comb_pos, sizeof(kt->comb_pos));
+    std::memcpy(kt->dct2, e->host.dct2, sizeof(kt->dct2));
+    if (he == hipSuccess) he = hipMalloc((void**)&e->dev, sizeof(KernelTables));
+    if (he == hipSuccess) he = hipMemcpy(e->dev, kt, sizeof(KernelTables), hipMemcpyHostToDevice);
+    delete kt;
     if (he != hipSuccess) {
         if (e->dev) (void)hipFree(e->dev);
         delete e;

@@ -50,7 +50,8 @@ SZ_HD float hi16(uint32_t w) { return (float)(int16_t)(w >> 16); }
 // k1 < 10 of Y go to R, rows 10..19 stay in hi_a / hi_b until phase1_high stores them.
 // win points at the first sample of the window and must be 8-byte aligned.  The two columns
 // are transformed one after the other so that only one 20-point DFT is live in registers.
-SZ_HD void phase1(int u, const int16_t* win, float* R, const ExtractTables* T, v2f (&hi_a)[kHalfRows], v2f (&hi_b)[kHalfRows])
+template <class TT>
+SZ_HD void phase1(int u, const int16_t* win, float* R, const TT* T, v2f (&hi_a)[kHalfRows], v2f (&hi_b)[kHalfRows])
 {
     uint32_t ra[20], rb[20];
 #pragma unroll
@@ -126,7 +127,8 @@ SZ_HD void split_pair(v2f P, v2f Q, v2f w, float& pk, float& pn)
 // Phase 2: two 20-point DFTs over n2 (x0 = this lane's row of the first half, read before rows
 // 10..19 were stored; its row of the second half is read here), real-FFT split, power spectrum
 // into R[0..410].
-SZ_HD void phase2(int u, float* R, const ExtractTables* T, const v2f (&x0)[20])
+template <class TT>
+SZ_HD void phase2(int u, float* R, const TT* T, const v2f (&x0)[20])
 {
     const bool z = (u == 0);
     v2f x[20], ZA[20], ZB[20];
@@ -166,7 +168,8 @@ SZ_HD void phase3_load(int q, const float* R, float (&p)[kMelSteps])
     for (int st = 0; st < kMelSteps; ++st) p[st] = R[(kMelSteps + 1) * q + 1 + st];  // pslot(40 q + 1 + st)
 }
 
-SZ_HD void phase3_sweep(int q, float* R, const ExtractTables* T, const float (&p)[kMelSteps])
+template <class TT>
+SZ_HD void phase3_sweep(int q, float* R, const TT* T, const float (&p)[kMelSteps])
 {
     const uint64_t flush = T->mel_flush[q];
     float wf[kMelSteps], wr[kMelSteps];
@@ -194,7 +197,8 @@ SZ_HD void phase3_sweep(int q, float* R, const ExtractTables* T, const float (&p
 
 // Phase 4: recombine the partial sums of filters q, q+10, q+20 and take the clamped log
 // (lib.rs:309).  Every filter reads kMaxComb slots; the unused ones hold 0.
-SZ_HD void phase4(int q, float* R, const ExtractTables* T)
+template <class TT>
+SZ_HD void phase4(int q, float* R, const TT* T)
 {
     int pos[3][kMaxComb];
 #pragma unroll
@@ -219,7 +223,8 @@ SZ_HD void phase4(int q, float* R, const ExtractTables* T)
 }
 
 // Phase 5: DCT-II coefficients q and q+10 (lib.rs:312-315).
-SZ_HD void phase5(int q, const float* R, const ExtractTables* T, float& c_lo, float& c_hi)
+template <class TT>
+SZ_HD void phase5(int q, const float* R, const TT* T, float& c_lo, float& c_hi)
 {
     float s0 = 0.0f, s1 = 0.0f;
 #pragma unroll

@@ -64,6 +64,22 @@ struct ExtractTables {
     float mel_dense[kMels][kBins];    // the full filterbank, kept for inspection / tests
 };
 
+// What the kernel reads of the tables, 13 KB: a workgroup keeps a copy in LDS (the per-lane table reads,
+// ~150 per group of windows, then cost an LDS access instead of a trip through the vector L1, which the
+// PCM stream keeps evicting).  Member names and shapes equal ExtractTables', so the phase functions take
+// either.
+struct KernelTables {
+    float twa[20][kGroup][2];
+    float twb[20][kGroup][2];
+    float sw[kSplitSlots][kGroup][2];
+    int32_t pk[kSplitSlots][kGroup][2];
+    float melw[kMelSteps][kGroup][2];
+    uint64_t mel_flush[kGroup];
+    alignas(16) int32_t comb_pos[32][kMaxComb];
+    float dct2[kMels][kGroup][2];
+};
+static_assert(sizeof(KernelTables) % 16 == 0, "copied in 16-byte pieces");
+
 // Fills *t.  Returns 0, or a negative number if the filterbank does not have the
 // "each bin feeds at most two adjacent triangles" structure the sweep relies on.
 int build_extract_tables(ExtractTables* t);

@@ -38,7 +38,7 @@ struct Segment {
 
 struct Extractor {
     ExtractTables host;
-    ExtractTables* dev = nullptr;
+    KernelTables* dev = nullptr;  // the part of `host` the kernel reads
     int device = 0;
 };
 
