@@ -5,7 +5,8 @@
 //                     A wavefront works on 6 windows at a time, 10 lanes per window; the
 //                     800-point real DFT is a 400-point complex FFT done as two register
 //                     passes of 20-point DFTs with one exchange through LDS (see
-//                     extract_phases.h).  Waves never synchronise with each other.
+//                     extract_phases.h).  The tables the phases read are copied into LDS once per
+//                     workgroup; after that the waves never synchronise with each other.
 //   finish_kernel     deltas with edge replication at file boundaries, concat and per-frame
 //                     z-score (lib.rs:212-228, 321-342); streams 80 B in, 240 B out per window.
 #include <algorithm>
