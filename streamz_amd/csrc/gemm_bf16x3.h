@@ -279,5 +279,171 @@ __global__ __launch_bounds__(XW_THREADS) void gemm_x3w_kernel(GemmArgs g)
     }
 }
 
+
+// ---- the same 256 x 256 walking structure on v_mfma_f32_32x32x2_f32 (exact f32) ---------------
+// LDS: two stages of [256][16 k] f32 per operand, row stride 20 floats (80 bytes, conflict-free
+// 16-byte reads).  One MFMA adds two k values, that of lanes 0-31 and that of lanes 32-63: step s of a
+// stage pairs k = s with k = s + 8, so that the eight values a lane needs from its row are contiguous.
+typedef float v4f __attribute__((ext_vector_type(4)));  // a plain vector: arrays of it stay in registers
+constexpr int FW_LD = 20;                    // floats per LDS row
+constexpr int FW_OPER = 256 * FW_LD;         // one operand, one stage
+constexpr int FW_STAGE = 2 * FW_OPER;
+constexpr size_t FW_LDS_BYTES = 2 * FW_STAGE * sizeof(float);
+
+template <int SRC> struct FWOperand;
+
+template <> struct FWOperand<X3_ROWS_F32> {
+    v4f f[4];  // f[2 j + h]: rows t / 4 + 128 j, k values 16 h + 4 (t % 4) ...
+    __device__ __forceinline__ void load(const void* base, int ld, int r0, int r_max, int k0)
+    {
+        const float* b = (const float*)base + k0 + 4 * (threadIdx.x & 3);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int row = min(r0 + (int)(threadIdx.x >> 2) + 128 * j, r_max - 1);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) f[2 * j + h] = *reinterpret_cast<const v4f*>(b + (size_t)row * ld + 16 * h);
+        }
+    }
+    template <int H> __device__ __forceinline__ void stash(float* S) const
+    {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            *reinterpret_cast<v4f*>(S + ((threadIdx.x >> 2) + 128 * j) * FW_LD + 4 * (threadIdx.x & 3)) = f[2 * j + H];
+    }
+};
+
+template <> struct FWOperand<X3_KROWS_F32> {
+    float f[16];  // f[8 h + j]: column t % 256, k = 16 h + 8 (t / 256) + j
+    __device__ __forceinline__ void load(const void* base, int ld, int c0, int, int k0)
+    {
+        const float* b = (const float*)base + (size_t)(k0 + 8 * (int)(threadIdx.x >> 8)) * ld + c0 + (threadIdx.x & 255);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) f[i] = b[(size_t)(16 * (i >> 3) + (i & 7)) * ld];
+    }
+    template <int H> __device__ __forceinline__ void stash(float* S) const
+    {
+        float* at = S + (threadIdx.x & 255) * FW_LD + 8 * (threadIdx.x >> 8);
+        *reinterpret_cast<v4f*>(at) = v4f{f[8 * H], f[8 * H + 1], f[8 * H + 2], f[8 * H + 3]};
+        *reinterpret_cast<v4f*>(at + 4) = v4f{f[8 * H + 4], f[8 * H + 5], f[8 * H + 6], f[8 * H + 7]};
+    }
+};
+
+// A = g.A as for gemm_x3w_kernel; B = g.B [N][K] f32 (X3_ROWS_F32) or [K][N] (X3_KROWS_F32).
+template <int ASRC, int BSRC, int EPI, int TAG>
+__global__ __launch_bounds__(XW_THREADS) void gemm_f32w_kernel(GemmArgs g)
+{
+    constexpr int TN = 4, WN = 128;
+    extern __shared__ __attribute__((aligned(16))) unsigned char xw_lds[];
+    float* L = reinterpret_cast<float*>(xw_lds);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int a_off = (wm * 64 + l31) * FW_LD + 8 * half;
+    const int b_off = FW_OPER + (wn * WN + l31) * FW_LD + 8 * half;
+
+    const int n_tiles = g.tiles_x * g.tiles_y * g.tiles_z;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd = (int)gridDim.x >> 3;
+    const int run = (n_tiles + 7) >> 3;
+    const int run_end = min(n_tiles, (xcd + 1) * run);
+    int tile = xcd * run + slot;
+    if (tile >= run_end) return;
+    struct Pos { int m0, n0, k_begin, k_end, bz; };
+    auto place = [&](int t) {
+        Pos p;
+        const int bx = t % g.tiles_x, by = (t / g.tiles_x) % g.tiles_y;
+        p.bz = t / (g.tiles_x * g.tiles_y);
+        p.m0 = by * XW_TM; p.n0 = bx * XW_TN;
+        p.k_begin = p.bz * g.k_chunk;
+        p.k_end = min(g.K, p.k_begin + g.k_chunk);
+        return p;
+    };
+    Pos cur = place(tile);
+
+    FWOperand<ASRC> fa;
+    FWOperand<BSRC> fb;
+    fa.load(g.A, g.lda, cur.m0, g.M, cur.k_begin);
+    fb.load(g.B, g.ldb, cur.n0, g.N, cur.k_begin);
+    fa.template stash<0>(L);
+    fb.template stash<0>(L + FW_OPER);
+    __syncthreads();
+
+    while (true) {
+        float* C = g.C;
+        if (EPI == EPI_SLAB) C += (size_t)cur.bz * (g.slab_stride ? (size_t)g.slab_stride : (size_t)g.M * (size_t)g.ldc);
+        f32x16 acc[2][TN];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+        if (EPI == EPI_SLAB && g.slab_add) {
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) {
+                    const int col = cur.n0 + wn * WN + tn * 32 + l31;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = cur.m0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                        acc[tm][tn][r] = C[(size_t)row * g.ldc + col];
+                    }
+                }
+        }
+        const int next = tile + per_xcd;
+        const bool has_next = next < run_end;
+        const Pos nxt = has_next ? place(next) : cur;
+
+        v4f a[2][2];
+        auto load_a = [&](const float* S) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) a[t][q] = *reinterpret_cast<const v4f*>(S + a_off + t * 32 * FW_LD + 4 * q);
+        };
+        auto multiply = [&](const float* S, int tn0) {  // column tiles tn0, tn0 + 1
+#pragma unroll
+            for (int tn = tn0; tn < tn0 + 2; ++tn) {
+                v4f b[2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) b[q] = *reinterpret_cast<const v4f*>(S + b_off + tn * 32 * FW_LD + 4 * q);
+                const float bv[8] = {b[0].x, b[0].y, b[0].z, b[0].w, b[1].x, b[1].y, b[1].z, b[1].w};
+#pragma unroll
+                for (int tm = 0; tm < 2; ++tm) {
+                    const float av[8] = {a[tm][0].x, a[tm][0].y, a[tm][0].z, a[tm][0].w, a[tm][1].x, a[tm][1].y, a[tm][1].z, a[tm][1].w};
+                    f32x16 c = acc[tm][tn];
+#pragma unroll
+                    for (int st = 0; st < 8; ++st) c = __builtin_amdgcn_mfma_f32_32x32x2f32(av[st], bv[st], c, 0, 0, 0);
+                    acc[tm][tn] = c;
+                }
+            }
+        };
+        for (int k0 = cur.k_begin; k0 < cur.k_end; k0 += 32) {
+            const bool last = k0 + 32 >= cur.k_end;
+            const int fm0 = last ? nxt.m0 : cur.m0, fn0 = last ? nxt.n0 : cur.n0;
+            const int fk = last ? (has_next ? nxt.k_begin : k0) : k0 + 32;
+            load_a(L);
+            fa.template stash<1>(L + FW_STAGE);
+            fb.template stash<1>(L + FW_STAGE + FW_OPER);
+            fa.load(g.A, g.lda, fm0, g.M, fk);
+            fb.load(g.B, g.ldb, fn0, g.N, fk);
+            multiply(L, 0);
+            multiply(L, 2);
+            __syncthreads();
+            load_a(L + FW_STAGE);
+            multiply(L + FW_STAGE, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            fa.template stash<0>(L);
+            fb.template stash<0>(L + FW_OPER);
+            multiply(L + FW_STAGE, 2);
+            __syncthreads();
+        }
+        finish_tile<EPI, XW_TM, TN, WN>(g, C, acc, cur.m0, cur.n0, wm, wn, l31, half);
+        if (!has_next) break;
+        tile = next;
+        cur = nxt;
+    }
+}
+
 }  // namespace gemm
 }  // namespace sz

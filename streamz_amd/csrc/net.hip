@@ -82,6 +82,30 @@ int launch_gemm_x3(GemmArgs g, int splits, hipStream_t s)
     return SZH_OK;
 }
 
+// The f32 products with a row-major first operand on 256 x 256 tiles walked by one workgroup per CU
+// (gemm_f32w_kernel): B as [N][K].
+template <int EPI, int TAG>
+int launch_gemm_f32w(GemmArgs g, hipStream_t s)
+{
+    if (g.M <= 0 || g.N <= 0) return SZH_OK;
+    if (int rc = allow_dynamic_lds((const void*)gemm_f32w_kernel<X3_ROWS_F32, X3_ROWS_F32, EPI, TAG>, FW_LDS_BYTES)) return rc;
+    ProfScope prof(kGemmTagName[TAG], s);
+    g.tiles_x = (g.N + XW_TN - 1) / XW_TN; g.tiles_y = (g.M + XW_TM - 1) / XW_TM; g.tiles_z = 1;
+    const int tiles = g.tiles_x * g.tiles_y;
+    const int blocks = std::min((tiles + 7) / 8 * 8, compute_units() / 8 * 8);
+    hipLaunchKernelGGL((gemm_f32w_kernel<X3_ROWS_F32, X3_ROWS_F32, EPI, TAG>), dim3(blocks), dim3(XW_THREADS), FW_LDS_BYTES, s, g);
+    SZ_HIP(hipGetLastError());
+    return SZH_OK;
+}
+
+// whether the hidden-layer forward product and its delta take that kernel: whole 256-wide tiles in both
+// hidden dimensions and at least two rounds of tiles per CU (below that the 128-wide tiles, of which
+// three workgroups fit a CU, are faster)
+inline bool use_wide_f32(const Net* n, uint64_t rows)
+{
+    return n->h1 % 256 == 0 && n->h2 % 256 == 0 && (rows / 256) * (std::min(n->h1, n->h2) / 256) >= 512;
+}
+
 // whether a call of `rows` rows takes the split-bf16 kernels: opted in, whole 256-wide tiles in both
 // hidden dimensions, and enough rows that 256-row tiles are not mostly padding
 inline bool use_x3(const Net* n, uint64_t rows)
@@ -1352,7 +1376,7 @@ int prepare_w2_planes(Net* n, bool backward, bool transposed_ready, hipStream_t 
 // hidden layers of `rows` rows (rows <= workspace capacity): h1, h2 in the workspace.  With x3 the
 // second layer runs on the split-bf16 kernel and prepare_w2_planes has been called.
 int forward_hidden(Net* n, const float* x, uint64_t rows, bool relu2, hipStream_t s, uint32_t* relu_mask = nullptr,
-                   int ldx = 0, bool x3 = false)
+                   int ldx = 0, bool x3 = false, bool wide = false)
 {
     Workspace& w = n->ws;
     const float* P = n->d_params;
@@ -1371,6 +1395,10 @@ int forward_hidden(Net* n, const float* x, uint64_t rows, bool relu2, hipStream_
         g.B = (const float*)w.w2s; g.ldb = n->h1; g.b_plane = (uint64_t)n->h1 * n->h2;
         return relu2 ? launch_gemm_x3<X3_ROWS_F32, X3_ROWS_SPLIT, EPI_BIAS_RELU, T_FWD2>(g, 1, s)
                      : launch_gemm_x3<X3_ROWS_F32, X3_ROWS_SPLIT, EPI_BIAS_TANH, T_FWD2>(g, 1, s);
+    }
+    if (wide) {  // B as [hidden2][hidden1]: w.w2t, which the caller has filled
+        g.B = w.w2t; g.ldb = n->h1;
+        return relu2 ? launch_gemm_f32w<EPI_BIAS_RELU, T_FWD2>(g, s) : launch_gemm_f32w<EPI_BIAS_TANH, T_FWD2>(g, s);
     }
     return relu2 ? launch_gemm<A_ROWS, B_KROWS, EPI_BIAS_RELU, T_FWD2>(g, 1, s)
                  : launch_gemm<A_ROWS, B_KROWS, EPI_BIAS_TANH, T_FWD2>(g, 1, s);
@@ -1559,10 +1587,16 @@ int net_forward_dev(Net* n, const float* x_dev, uint64_t rows, float* out_dev, F
     if (rc) return rc;
     const uint32_t ow = kind == kFwdProbs ? n->out : n->h2;
     const bool x3 = use_x3(n, rows);
+    const bool wide = !x3 && use_wide_f32(n, rows);
     if (x3 && (rc = prepare_w2_planes(n, false, false, s))) return rc;
+    if (wide) {
+        hipLaunchKernelGGL(transpose_kernel, dim3((n->h2 + 31) / 32, (n->h1 + 31) / 32), dim3(256), 0, s,
+                           n->d_params + n->off_w2(), (int)n->h1, (int)n->h2, n->ws.w2t);
+        SZ_HIP(hipGetLastError());
+    }
     for (uint64_t r0 = 0; r0 < rows; r0 += chunk_rows(n)) {
         const uint64_t R = std::min<uint64_t>(chunk_rows(n), rows - r0);
-        rc = forward_hidden(n, x_dev + r0 * n->in, R, kind == kFwdEmbedRelu, s, nullptr, 0, x3);
+        rc = forward_hidden(n, x_dev + r0 * n->in, R, kind == kFwdEmbedRelu, s, nullptr, 0, x3, wide);
         if (rc) return rc;
         float* o = out_dev + r0 * ow;
         if (kind == kFwdProbs) {
@@ -1646,6 +1680,7 @@ int net_accumulate(Net* n, const AccumArgs& a, hipStream_t s)
     }
     SZ_HIP(hipGetLastError());
     const bool x3 = use_x3(n, a.rows);
+    const bool wide = !x3 && use_wide_f32(n, a.rows);
     if (x3 && (rc = prepare_w2_planes(n, true, true, s))) return rc;
     float* w3tab = w.w2t + (uint64_t)n->h1 * n->h2;  // behind the transposed w2 (a multiple of 4 floats in)
     // Every chunk adds its split-K partials into the same slabs (the first one overwrites them);
@@ -1697,7 +1732,7 @@ int net_accumulate(Net* n, const AccumArgs& a, hipStream_t s)
         SZ_HIP(hipGetLastError());
         // the ReLU derivative travels as one bit per unit
         uint32_t* relu_mask = w.mask;
-        rc = forward_hidden(n, w.xd, R, false, s, relu_mask, w.ldx, x3);
+        rc = forward_hidden(n, w.xd, R, false, s, relu_mask, w.ldx, x3, wide);
         if (rc) return rc;
         if (use_head) {
             HeadArgs h{};
@@ -1788,6 +1823,9 @@ int net_accumulate(Net* n, const AccumArgs& a, hipStream_t s)
             g.B = (const float*)(w.w2s + 3 * ((uint64_t)n->h1 * n->h2 / 2)); g.ldb = n->h2;
             g.b_plane = (uint64_t)n->h1 * n->h2;
             rc = launch_gemm_x3<X3_ROWS_F32, X3_ROWS_SPLIT, EPI_MUL_MASK, T_DELTA1>(g, 1, s);
+        } else if (wide) {  // B as [hidden1][hidden2]: w2 itself
+            g.B = P + n->off_w2(); g.ldb = n->h2;
+            rc = launch_gemm_f32w<EPI_MUL_MASK, T_DELTA1>(g, s);
         } else {
             rc = relu_mask ? launch_gemm<A_ROWS, B_KROWS, EPI_MUL_MASK, T_DELTA1>(g, 1, s)
                            : launch_gemm<A_ROWS, B_KROWS, EPI_MUL_DRELU, T_DELTA1>(g, 1, s);

@@ -91,11 +91,15 @@ def test_two_rank_processes_on_one_gpu(tmp_path):
     from oracle import pyoracle as po
     import two_rank_child as tr
 
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE="2")
-    procs = [subprocess.Popen([sys.executable, "-X", "faulthandler", os.path.join(ROOT, "tests", "two_rank_child.py"), str(tmp_path)],
-                              env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE,
-                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
-    outs = [p.communicate(timeout=300)[0] for p in procs]
+    for attempt in range(3):  # the port is free when it is picked, not necessarily when the ranks bind it
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE="2")
+        procs = [subprocess.Popen([sys.executable, "-X", "faulthandler", os.path.join(ROOT, "tests", "two_rank_child.py"), str(tmp_path)],
+                                  env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE,
+                                  stderr=subprocess.STDOUT, text=True) for r in range(2)]
+        outs = [p.communicate(timeout=300)[0] for p in procs]
+        if attempt < 2 and any(p.returncode != 0 and "EADDRINUSE" in o for p, o in zip(procs, outs)):
+            continue
+        break
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o[-4000:]
     r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
@@ -147,7 +151,16 @@ def test_rccl_communicator_single_rank_in_place():
 
 
 def _bench_line(cmd, env):
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    """cmd / env may be callables of a rendezvous port: the launch is repeated with another port when
+    the one picked was taken between picking and binding"""
+    for attempt in range(3):
+        port = _free_port()
+        c = cmd(port) if callable(cmd) else cmd
+        e = env(port) if callable(env) else env
+        r = subprocess.run(c, env=e, capture_output=True, text=True, timeout=600, cwd=ROOT)
+        if r.returncode != 0 and "EADDRINUSE" in r.stdout + r.stderr and attempt < 2:
+            continue
+        break
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
@@ -158,14 +171,15 @@ def test_bench_multi_rank_branch():
     small = ["--clips", "6", "--seconds", "5", "--steps", "2", "--warmup", "1", "--no-extras", "--no-cpu-baseline"]
     one = _bench_line([sys.executable, "bench.py", "--gpus", "1"] + small, dict(os.environ))
     # two ranks on the one GPU (gradient vectors summed on the host)
-    two = _bench_line([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                       "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), "bench.py", "--gpus", "2",
-                       "--share-gpu"] + small, dict(os.environ))
+    two = _bench_line(lambda port: [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                                    "--master-addr", "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "2",
+                                    "--share-gpu"] + small, dict(os.environ))
     assert two["n_gpus"] == 2 and two["config"]["windows_per_gpu"] == one["config"]["windows_per_gpu"]
     assert two["mean_loss_last_step"] is not None and np.isfinite(two["mean_loss_last_step"])
     # the RCCL branch with a single rank: same numbers as the plain single-GPU run
-    rccl = _bench_line([sys.executable, "bench.py", "--gpus", "1"] + small, dict(os.environ, BENCH_FORCE_DIST="1",
-                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0"))
+    rccl = _bench_line([sys.executable, "bench.py", "--gpus", "1"] + small,
+                       lambda port: dict(os.environ, BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                                         RANK="0", WORLD_SIZE="1", LOCAL_RANK="0"))
     assert "RCCL" in rccl["config"]["batch"]
     assert rccl["mean_loss_last_step"] == one["mean_loss_last_step"]
 

@@ -53,6 +53,17 @@ void launch_w(GemmArgs g, int splits, int max_blocks = 256)
     hipLaunchKernelGGL((gemm_x3w_kernel<ASRC, BSRC, EPI, TAG>), dim3(blocks), dim3(XW_THREADS), XW_LDS_BYTES, 0, g);
 }
 
+template <int ASRC, int BSRC, int EPI>
+void launch_fw(GemmArgs g, int splits, int max_blocks = 256)
+{
+    static bool once = false;
+    if (!once) { CK(hipFuncSetAttribute((const void*)gemm_f32w_kernel<ASRC, BSRC, EPI, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FW_LDS_BYTES)); once = true; }
+    g.tiles_x = (g.N + 255) / 256; g.tiles_y = (g.M + 255) / 256; g.tiles_z = splits;
+    const int tiles = g.tiles_x * g.tiles_y * g.tiles_z;
+    const int blocks = std::min((tiles + 7) / 8 * 8, max_blocks);
+    hipLaunchKernelGGL((gemm_f32w_kernel<ASRC, BSRC, EPI, 0>), dim3(blocks), dim3(XW_THREADS), FW_LDS_BYTES, 0, g);
+}
+
 template <class K> float time_us(K launch, int iters)
 {
     hipEvent_t a, b;
@@ -99,6 +110,15 @@ int main(int argc, char** argv)
             ref[(size_t)r * H2 + n] = std::tanh(s);
         }
         std::printf("fwd2   (tanh out)  max |err| vs f64: f32 kernel %.3e   bf16x3 kernel %.3e\n", maxerr(download(dh2, ref.size()), ref), maxerr(download(dh2w, ref.size()), ref));
+        {
+            float* dh2f = dev<float>((size_t)R * H2);
+            GemmArgs gf = g; gf.C = dh2f; gf.B = dw2t; gf.ldb = H1;
+            launch_fw<X3_ROWS_F32, X3_ROWS_F32, EPI_BIAS_TANH>(gf, 1, 8);
+            CK(hipDeviceSynchronize());
+            auto a1 = download(dh2, ref.size()), a2 = download(dh2f, ref.size());
+            double d = 0; for (size_t i = 0; i < a1.size(); ++i) d = std::fmax(d, std::fabs((double)a1[i] - a2[i]));
+            std::printf("fwd2   wide f32 kernel: max |err| vs f64 %.3e, max |difference| to the 128-tile f32 kernel %.3e\n", maxerr(a2, ref), d);
+        }
         // delta1 = (d2 . w2^T) * [h1 > 0]
         g = GemmArgs{};
         g.A = dd2; g.lda = H2; g.B = dw2t; g.ldb = H1; g.C = dd1; g.ldc = H1; g.M = R; g.N = H1; g.K = H2; g.k_chunk = H2; g.aux = dh1; g.ldaux = H1; g.a_vec = 1; g.b_vec = 1;
@@ -171,6 +191,18 @@ int main(int argc, char** argv)
         const float t_f2w = time_us([&] { launch_w<X3_ROWS_F32, X3_ROWS_SPLIT, EPI_BIAS_TANH>(f2x, 1); }, 5);
         const float t_dlw = time_us([&] { launch_w<X3_ROWS_F32, X3_ROWS_SPLIT, EPI_MUL_DRELU>(dlx, 1); }, 5);
         const float t_dww = time_us([&] { launch_w<X3_KROWS_F32, X3_KROWS_F32, EPI_SLAB>(dww, splits_w); }, 5);
+        {
+            std::vector<float> hwt((size_t)H1 * H2);
+            for (int k = 0; k < H1; ++k) for (int n = 0; n < H2; ++n) hwt[(size_t)n * H1 + k] = hw[(size_t)k * H2 + n];
+            float* w2t = upload(hwt);
+            GemmArgs f2f = f2; f2f.B = w2t; f2f.ldb = H1;          // [n = H2][k = H1]
+            GemmArgs dlf = dl; dlf.B = w2; dlf.ldb = H2;            // [n = H1][k = H2]: w2 itself
+            GemmArgs dwf = dww;
+            const float t1 = time_us([&] { launch_fw<X3_ROWS_F32, X3_ROWS_F32, EPI_BIAS_TANH>(f2f, 1); }, 5);
+            const float t2 = time_us([&] { launch_fw<X3_ROWS_F32, X3_ROWS_F32, EPI_MUL_DRELU>(dlf, 1); }, 5);
+            const float t3 = time_us([&] { launch_fw<X3_KROWS_F32, X3_KROWS_F32, EPI_SLAB>(dwf, splits_w); }, 5);
+            std::printf("  wide f32 kernel: fwd2 %8.1f (%.1f)  delta1 %8.1f (%.1f)  dw2 %8.1f (%.1f)\n", t1, flop / t1 * 1e-6, t2, flop / t2 * 1e-6, t3, flop / t3 * 1e-6);
+        }
         std::printf("rows %zu, %d x %d   (us per launch, f32-equivalent TFLOP/s)\n", R, H1, H2);
         std::printf("  fwd2    f32 %8.1f (%.1f)   bf16x3 %8.1f (%.1f)\n", t_f2, flop / t_f2 * 1e-6, t_f2w, flop / t_f2w * 1e-6);
         std::printf("  delta1  f32 %8.1f (%.1f)   bf16x3 %8.1f (%.1f)\n", t_dl, flop / t_dl * 1e-6, t_dlw, flop / t_dlw * 1e-6);
