@@ -9,6 +9,10 @@
 // Splitting happens once per element on the way into LDS; weights arrive pre-split from
 // split_planes_kernel.  The accumulator layout is that of the f32 kernel (gemm_kernel.h), so the
 // epilogues are shared with it.
+//
+// The file's second kernel, gemm_f32w_kernel, is the same 256 x 256 walking structure on
+// v_mfma_f32_32x32x2_f32 with unsplit f32 operands: the exact-f32 kernel for products large enough
+// to give every compute unit several such tiles.
 #pragma once
 #include "gemm_kernel.h"
 

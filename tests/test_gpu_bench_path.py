@@ -23,9 +23,10 @@ def po():
     return pyoracle
 
 
-def _oracle_grad_threads(onet, x, labels, threads=16):
-    """oracle gradient of many rows, the rows spread over host threads (ctypes releases the GIL)"""
-    parts = np.array_split(np.arange(len(x)), threads)
+def _oracle_grad_threads(onet, x, labels, threads=16, pieces=None):
+    """oracle gradient of many rows, the rows spread over host threads (ctypes releases the GIL);
+    each of the `pieces` partial sums is the oracle's f32 sum, the pieces are added in f64"""
+    parts = np.array_split(np.arange(len(x)), pieces or threads)
     with ThreadPoolExecutor(threads) as pool:
         gs = list(pool.map(lambda ix: onet.grad(x[ix[0]:ix[-1] + 1], labels=labels[ix[0]:ix[-1] + 1]).astype(np.float64),
                            [p for p in parts if len(p)]))
@@ -105,6 +106,66 @@ def test_accumulate_dev_at_the_wide_configuration(sz, po, gemm):
     assert g[-1] == n
     probs = onet.forward(x[:1280])   # >= 1024 rows, so that the forward pass also takes the chosen kernels
     np.testing.assert_allclose(net.forward(x[:1280]), probs, atol=1e-4)
+
+
+def test_accumulate_dev_at_a_row_count_that_takes_the_walking_f32_kernel(sz, po):
+    """From 512 tiles of 256 x 256 per product on (131 072 rows at 60-512-256-16) fwd2 and delta1 run on
+    the 256-tile walking kernel: 140 003 rows (a ragged last tile) against the oracle's gradient and
+    probabilities, and against the same rows fed in pieces small enough for the 128-tile kernel."""
+    import torch
+    rng = np.random.default_rng(43)
+    dims = (60, 512, 256, 16)
+    onet = po.Net(*dims)
+    params = [rng.uniform(-0.5, 0.5, s).astype(np.float32) for s in onet.shapes()]
+    onet.set_params(params)
+    net = sz.SimpleNeuralNet(*dims, init=params)
+    assert net.get_gemm() == "f32"
+    n = 140003
+    x = rng.standard_normal((n, 60)).astype(np.float32)
+    x[n - 2] = 0.0   # an all-zero row does not count (lib.rs:607-609)
+    live = np.any(x != 0.0, axis=1)
+    labels = rng.integers(0, 16, n).astype(np.int32)
+    dx, dl = torch.from_numpy(x).cuda(), torch.from_numpy(labels).cuda()
+    s = torch.cuda.current_stream().cuda_stream
+    net.zero_grad_dev(s)
+    net.accumulate_dev(dx.data_ptr(), dl.data_ptr(), n, stream=s)
+    torch.cuda.synchronize()
+    g = grad_view(net).cpu().numpy()
+    want = _oracle_grad_threads(onet, x[live], labels[live], pieces=512)   # short f32 sums on the oracle's side
+    scale = np.abs(want).max()
+    # Among 72 M first-layer pre-activations a few lie within an f32 rounding of zero, and there the
+    # ReLU decision depends on how the 60-term sum was rounded (the oracle multiplies and adds, the
+    # matrix instruction fuses).  Such a decision moves the unit's column of dW1, its db1 entry and its
+    # row of dW2 by one row's contribution: those entries are compared at a looser bound.
+    w1, b1 = params[0].astype(np.float64), params[1].astype(np.float64)
+    near = np.zeros(dims[1], bool)
+    for r0 in range(0, n, 20000):
+        z = x[r0:r0 + 20000].astype(np.float64) @ w1 + b1
+        near |= (np.abs(z) < 1.5e-6).any(axis=0)
+    assert near.sum() < 64   # of 512 units
+    loose = np.zeros(want.size, bool)
+    loose[:60 * dims[1]].reshape(60, dims[1])[:, near] = True
+    loose[60 * dims[1]:61 * dims[1]][near] = True
+    off_w2 = 61 * dims[1]
+    loose[off_w2:off_w2 + dims[1] * dims[2]].reshape(dims[1], dims[2])[near, :] = True
+    np.testing.assert_allclose(g[:-2][~loose], want[~loose], atol=2e-5 * scale)
+    np.testing.assert_allclose(g[:-2][loose], want[loose], atol=2e-4 * scale)
+    assert g[-1] == n - 1
+    # the same rows in four calls, each below the walking kernel's threshold
+    net.zero_grad_dev(s)
+    step = 40000
+    for r0 in range(0, n, step):
+        rows = min(step, n - r0)
+        net.accumulate_dev(dx[r0:].data_ptr(), dl[r0:].data_ptr(), rows, stream=s)
+    torch.cuda.synchronize()
+    g4 = grad_view(net).cpu().numpy()
+    np.testing.assert_allclose(g[:-2], g4[:-2], atol=2e-6 * scale)
+    assert g4[-1] == n - 1 and abs(g4[-2] - g[-2]) < 1e-6 * g[-2]
+    # forward: the last rows sit in the ragged tile
+    probs = net.forward(x)
+    tail = slice(n - 600, n)
+    np.testing.assert_allclose(probs[tail], onet.forward(x[tail]), atol=2e-5)
+    np.testing.assert_allclose(probs[:600], onet.forward(x[:600]), atol=2e-5)
 
 
 def _shuffle_orders(seed, n_win, epochs):

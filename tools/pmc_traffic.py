@@ -16,7 +16,7 @@ OTHER = {"prep_rows_kernel": "prep", "head_mfma_kernel": "head", "head_wide_kern
 
 
 def tag_of(name):
-    m = re.search(r"gemm_kernel<\d+, \d+, \d+, (\d+),", name) or re.search(r"gemm_x3w_kernel<\d+, \d+, \d+, (\d+)>", name)
+    m = re.search(r"gemm_kernel<\d+, \d+, \d+, (\d+),", name) or re.search(r"gemm_(?:x3|f32)w_kernel<\d+, \d+, \d+, (\d+)>", name)
     if m:
         return GEMM_TAGS[int(m.group(1))]
     for key, tag in OTHER.items():
