@@ -86,6 +86,7 @@ struct Workspace {
     uint32_t* w2s = nullptr;      // bf16 planes of w2^T and of w2 (split-bf16 kernels), two bf16 per word
     uint32_t* w3s = nullptr;      // the same for w3^T and w3 (GEMM output path only)
     float* w3t = nullptr;         // w3 transposed, the source of its planes
+    float* w1t = nullptr;         // [hidden1][ldx]: w1 transposed, zeros behind its `in` columns
     double* stat_slab = nullptr;  // per-workgroup {loss, live rows} partials of the head kernels
     uint64_t slab_floats = 0;
     // regions of `slab` (float offsets): split-K partials of dW1|db1, dW2, dW3|db3 and db2

@@ -1159,6 +1159,17 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
         if (c0 + i < cols && r0 + tx < rows) out[(size_t)(c0 + i) * rows + r0 + tx] = t[tx][i];
 }
 
+// out[c][0 .. ld) = in[0 .. rows)[c], zeros behind: the first layer's weights as the [N][K] operand of
+// a product over the prepared rows' ld columns (whose columns from `rows` on hold 1, 0, 0, ...)
+__global__ __launch_bounds__(256) void pad_transpose_kernel(const float* __restrict__ in, int rows, int cols, int ld,
+                                                            float* __restrict__ out)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= cols * ld) return;
+    const int c = i / ld, k = i % ld;
+    out[i] = k < rows ? in[(size_t)k * cols + c] : 0.0f;
+}
+
 // ---- column sums (bias gradients), split over rows into slabs ------------------------
 __global__ void colsum_kernel(const float* __restrict__ D, uint64_t rows, int cols, int ld, int rows_per_split,
                               int add, float* __restrict__ slab, uint64_t slab_stride)
@@ -1304,6 +1315,7 @@ int ensure_workspace(Net* n, uint64_t rows)
     if (w.w2s) { (void)hipFree(w.w2s); w.w2s = nullptr; }
     if (w.w3s) { (void)hipFree(w.w3s); w.w3s = nullptr; }
     if (w.w3t) { (void)hipFree(w.w3t); w.w3t = nullptr; }
+    if (w.w1t) { (void)hipFree(w.w1t); w.w1t = nullptr; }
     if (w.live) { (void)hipFree(w.live); w.live = nullptr; }
     if (w.mask) { (void)hipFree(w.mask); w.mask = nullptr; }
     if (w.stat_slab) { (void)hipFree(w.stat_slab); w.stat_slab = nullptr; }
@@ -1336,6 +1348,7 @@ int ensure_workspace(Net* n, uint64_t rows)
     SZ_HIP(hipMalloc((void**)&w.w2s, 2 * 3 * ((uint64_t)n->h1 * n->h2 + 1) * sizeof(uint16_t)));
     SZ_HIP(hipMalloc((void**)&w.w3s, 2 * 3 * ((uint64_t)n->h2 * n->out + 2) * sizeof(uint16_t)));
     SZ_HIP(hipMalloc((void**)&w.w3t, ((uint64_t)n->h2 * n->out + 1) * sizeof(float)));
+    SZ_HIP(hipMalloc((void**)&w.w1t, (uint64_t)n->h1 * w.ldx * sizeof(float)));
     SZ_HIP(hipMalloc((void**)&w.stat_slab, 2 * head_blocks * sizeof(double)));
     SZ_HIP(hipMalloc((void**)&w.w2t, ((uint64_t)n->h1 * n->h2 + 8 * 64 * 4 * ((n->h2 + 15) / 16)) * sizeof(float)));
     w.rows = R;
@@ -1376,7 +1389,7 @@ int prepare_w2_planes(Net* n, bool backward, bool transposed_ready, hipStream_t 
 // hidden layers of `rows` rows (rows <= workspace capacity): h1, h2 in the workspace.  With x3 the
 // second layer runs on the split-bf16 kernel and prepare_w2_planes has been called.
 int forward_hidden(Net* n, const float* x, uint64_t rows, bool relu2, hipStream_t s, uint32_t* relu_mask = nullptr,
-                   int ldx = 0, bool x3 = false, bool wide = false)
+                   int ldx = 0, bool x3 = false, bool wide = false, bool wide1 = false)
 {
     Workspace& w = n->ws;
     const float* P = n->d_params;
@@ -1385,8 +1398,14 @@ int forward_hidden(Net* n, const float* x, uint64_t rows, bool relu2, hipStream_
     g.B = P + n->off_w1(); g.ldb = n->h1; g.C = w.h1; g.ldc = n->h1;
     g.M = (int)rows; g.N = n->h1; g.K = n->in; g.k_chunk = n->in; g.bias = P + n->off_b1();
     g.mask = relu_mask;
-    int rc = relu_mask ? launch_gemm<A_ROWS, B_KROWS, EPI_BIAS_RELU_MASK, T_FWD1>(g, 1, s)
+    int rc;
+    if (wide1 && relu_mask && ldx) {  // prepared rows: K = ldx, B as [hidden1][ldx]: w.w1t, which the caller has filled
+        g.B = w.w1t; g.ldb = ldx; g.K = ldx; g.k_chunk = ldx;
+        rc = launch_gemm_f32w<EPI_BIAS_RELU_MASK, T_FWD1>(g, s);
+    } else {
+        rc = relu_mask ? launch_gemm<A_ROWS, B_KROWS, EPI_BIAS_RELU_MASK, T_FWD1>(g, 1, s)
                        : launch_gemm<A_ROWS, B_KROWS, EPI_BIAS_RELU, T_FWD1>(g, 1, s);
+    }
     if (rc) return rc;
     g = GemmArgs{};
     g.A = w.h1; g.lda = n->h1; g.B = P + n->off_w2(); g.ldb = n->h2; g.C = w.h2; g.ldc = n->h2;
@@ -1680,8 +1699,15 @@ int net_accumulate(Net* n, const AccumArgs& a, hipStream_t s)
     }
     SZ_HIP(hipGetLastError());
     const bool x3 = use_x3(n, a.rows);
-    const bool wide = !x3 && use_wide_f32(n, a.rows);
+    const bool wide1 = use_wide_f32(n, a.rows);  // the first layer's product (exact f32 in either mode)
+    const bool wide = !x3 && wide1;
     if (x3 && (rc = prepare_w2_planes(n, true, true, s))) return rc;
+    if (wide1) {
+        ProfScope prof("w2t", s);
+        hipLaunchKernelGGL(pad_transpose_kernel, dim3((n->h1 * w.ldx + 255) / 256), dim3(256), 0, s, P + n->off_w1(),
+                           (int)n->in, (int)n->h1, w.ldx, w.w1t);
+        SZ_HIP(hipGetLastError());
+    }
     float* w3tab = w.w2t + (uint64_t)n->h1 * n->h2;  // behind the transposed w2 (a multiple of 4 floats in)
     // Every chunk adds its split-K partials into the same slabs (the first one overwrites them);
     // the slabs are folded into the gradient vector once, after the last chunk.
@@ -1732,7 +1758,7 @@ int net_accumulate(Net* n, const AccumArgs& a, hipStream_t s)
         SZ_HIP(hipGetLastError());
         // the ReLU derivative travels as one bit per unit
         uint32_t* relu_mask = w.mask;
-        rc = forward_hidden(n, w.xd, R, false, s, relu_mask, w.ldx, x3, wide);
+        rc = forward_hidden(n, w.xd, R, false, s, relu_mask, w.ldx, x3, wide, wide1);
         if (rc) return rc;
         if (use_head) {
             HeadArgs h{};

@@ -109,8 +109,8 @@ def test_accumulate_dev_at_the_wide_configuration(sz, po, gemm):
 
 
 def test_accumulate_dev_at_a_row_count_that_takes_the_walking_f32_kernel(sz, po):
-    """From 512 tiles of 256 x 256 per product on (131 072 rows at 60-512-256-16) fwd2 and delta1 run on
-    the 256-tile walking kernel: 140 003 rows (a ragged last tile) against the oracle's gradient and
+    """From 512 tiles of 256 x 256 per product on (131 072 rows at 60-512-256-16) fwd1, fwd2 and delta1 run
+    on the 256-tile walking kernel: 140 003 rows (a ragged last tile) against the oracle's gradient and
     probabilities, and against the same rows fed in pieces small enough for the 128-tile kernel."""
     import torch
     rng = np.random.default_rng(43)
@@ -159,7 +159,9 @@ def test_accumulate_dev_at_a_row_count_that_takes_the_walking_f32_kernel(sz, po)
         net.accumulate_dev(dx[r0:].data_ptr(), dl[r0:].data_ptr(), rows, stream=s)
     torch.cuda.synchronize()
     g4 = grad_view(net).cpu().numpy()
-    np.testing.assert_allclose(g[:-2], g4[:-2], atol=2e-6 * scale)
+    # (the pieces' first layer runs on the other kernel too, with its own rounding of the near-zero sums)
+    np.testing.assert_allclose(g[:-2][~loose], g4[:-2][~loose], atol=2e-6 * scale)
+    np.testing.assert_allclose(g[:-2][loose], g4[:-2][loose], atol=2e-4 * scale)
     assert g4[-1] == n - 1 and abs(g4[-2] - g[-2]) < 1e-6 * g[-2]
     # forward: the last rows sit in the ragged tile
     probs = net.forward(x)
