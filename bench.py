@@ -227,11 +227,31 @@ def main():
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local_rank if multi else 0)
     sz._capi._check(sz.lib().szh_init(dev.index))
-    comm = None
+    comm, torch_rccl, comm_note = None, None, None
     if multi and not args.share_gpu:
-        ident = [sz.comm_unique_id() if rank == 0 else None]
+        err = None
+        try:
+            if os.environ.get("BENCH_FORCE_TORCH_RCCL"):
+                raise RuntimeError("BENCH_FORCE_TORCH_RCCL is set")
+            ident = [sz.comm_unique_id() if rank == 0 else None]
+        except Exception as e:  # noqa: BLE001 - whatever stops the library's communicator from coming up
+            ident, err = [None], repr(e)
         dist.broadcast_object_list(ident, src=0)
-        comm = sz.Comm(ident[0], rank, world)  # ncclCommInitRank: collective over the ranks
+        if ident[0] is not None:
+            try:
+                comm = sz.Comm(ident[0], rank, world)  # ncclCommInitRank: collective over the ranks
+            except Exception as e:  # noqa: BLE001
+                err = repr(e)
+        # every rank takes the same collective: if the library's communicator is missing anywhere, all
+        # ranks reduce the same library-owned gradient vector in place through torch's RCCL group instead
+        ok = torch.tensor([0 if comm is None else 1], dtype=torch.int32)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            comm = None
+            torch_rccl = dist.new_group(backend="nccl")
+            comm_note = "library communicator unavailable (%s): torch.distributed RCCL group on the same vector" % err
+            if rank == 0:
+                print("bench: " + comm_note, file=sys.stderr)
 
     # ---- synthetic, device-resident inputs
     pcm, offsets, lengths = synth_clips(args.clips, args.seconds, args.speakers, dev, first_clip=rank * args.clips)
@@ -261,6 +281,8 @@ def main():
         net.accumulate_dev(feats.data_ptr(), labels.data_ptr(), n_win, args.dropout, 1000 + k, stream)
         if comm is not None:
             comm.allreduce_grad(net, stream)  # gradients, loss and live-row count summed over ranks, in place
+        elif torch_rccl is not None:
+            dist.all_reduce(grad, group=torch_rccl)
         elif dist is not None:  # --share-gpu rehearsal
             host = grad.cpu()
             dist.all_reduce(host)
@@ -359,11 +381,13 @@ def main():
                          f"{args.speakers} speakers, net 60-{H1}-{H2}-{C}"),
             "windows_per_gpu": n_win,
             "batch": "one optimiser step per epoch over all windows (gradients summed on device"
-                     + (", one in-place RCCL all-reduce of the gradient vector across ranks)" if comm is not None else ")"),
+                     + (", one in-place RCCL all-reduce of the gradient vector across ranks)"
+                        if (comm is not None or torch_rccl is not None) else ")"),
             "epochs_per_step": 1,
             "dropout": args.dropout,
             "lr": args.lr,
             "parallelism": f"files sharded over {world} GPU(s)",
+            **({"collective_note": comm_note} if comm_note else {}),
         },
         "breakdown_ms": {"extract": t_ext_ms, "train_epoch": t_train_ms},
         "extract_windows_per_s": n_win / (t_ext_ms * 1e-3),

@@ -180,8 +180,14 @@ def test_bench_multi_rank_branch():
     rccl = _bench_line([sys.executable, "bench.py", "--gpus", "1"] + small,
                        lambda port: dict(os.environ, BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                                          RANK="0", WORLD_SIZE="1", LOCAL_RANK="0"))
-    assert "RCCL" in rccl["config"]["batch"]
+    assert "RCCL" in rccl["config"]["batch"] and "collective_note" not in rccl["config"]
     assert rccl["mean_loss_last_step"] == one["mean_loss_last_step"]
+    # the stand-in for a library communicator that does not come up: torch's RCCL group on the same vector
+    alt = _bench_line([sys.executable, "bench.py", "--gpus", "1"] + small,
+                      lambda port: dict(os.environ, BENCH_FORCE_DIST="1", BENCH_FORCE_TORCH_RCCL="1", MASTER_ADDR="127.0.0.1",
+                                        MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0"))
+    assert "torch.distributed RCCL group" in alt["config"]["collective_note"]
+    assert alt["mean_loss_last_step"] == one["mean_loss_last_step"]
 
 
 def test_train_epochs_sharded_is_the_device_epoch_loop_and_matches_the_oracle():
