@@ -1279,21 +1279,32 @@ __global__ void apply_kernel(float* __restrict__ params, const float* __restrict
 
 // Rows per launch.  Large enough that a launch is many rounds of workgroups per CU, so that the
 // prologues and epilogues of some overlap the matrix work of others, and that the fixed cost of the
-// ~7 launches per chunk is small (measured at 60-512-256: 49 152 rows, one round, is 15 % slower
-// per row; 393 216 -> 1 572 864 rows gains another 3 %).  The chunk is sized so that the
-// workspace, which holds every activation and delta of a chunk, stays near 10 GB.
+// ~7 launches per chunk and the partly filled last round of each are small (measured at 60-512-256:
+// 49 152 rows, one round, is 15 % slower per row; 393 216 -> 1 572 864 rows gains 3 %, 1 322 800 ->
+// 6 614 000 another 2 %).  The workspace holds every activation and delta of a chunk: it may take up to
+// 48 GB of the 288 GB, and no more than half of what was free when the process first asked.
 static const uint64_t kChunkRowsEnv = [] {
     // STREAMZ_CHUNK_ROWS overrides the rows per launch (a tuning knob; at least 256, multiple of 128)
     const char* e = std::getenv("STREAMZ_CHUNK_ROWS");
     const uint64_t v = e ? std::strtoull(e, nullptr, 10) : 0;
     return v >= 256 ? (v + 127) / 128 * 128 : (uint64_t)0;
 }();
+static uint64_t workspace_budget()
+{
+    static const uint64_t budget = [] {
+        size_t free_b = 0, total_b = 0;
+        uint64_t b = 48ull << 30;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) b = std::min<uint64_t>(b, free_b / 2);
+        return std::max<uint64_t>(b, 1ull << 30);
+    }();
+    return budget;
+}
 static uint64_t chunk_rows(const Net* n)
 {
     if (kChunkRowsEnv) return kChunkRowsEnv;
     const uint64_t per_row = 4ull * (64 + n->in + 2ull * n->h1 + 2ull * n->h2 + n->out);
-    const uint64_t r = (10ull << 30) / per_row;
-    return std::min<uint64_t>(std::max<uint64_t>(r, 131072), 1572864) / 128 * 128;
+    const uint64_t r = workspace_budget() / per_row;
+    return std::min<uint64_t>(std::max<uint64_t>(r, 131072), 8ull << 20) / 128 * 128;
 }
 // Most split-K slabs of a weight-gradient product: enough that tiles x splits is several
 // workgroups per CU (dW1 has only 4 column tiles, dW2 has 8 tiles)
