@@ -127,22 +127,32 @@ __global__ __launch_bounds__(256) void prep_rows_kernel(const float* __restrict_
                                                         float* __restrict__ xd, int ldx, uint8_t* __restrict__ live)
 {
     __shared__ unsigned int nz[kPrepRows];
+    __shared__ uint64_t row_key[kPrepRows];  // the row's half of uniform01's hash (rng.h)
     const uint64_t r0 = (uint64_t)blockIdx.x * kPrepRows;
     const int nr = (int)min((uint64_t)kPrepRows, rows - r0);
-    if (threadIdx.x < kPrepRows) nz[threadIdx.x] = 0;
+    const bool draw = !keep && dropout > 0.0f;
+    if (threadIdx.x < kPrepRows) {
+        nz[threadIdx.x] = 0;
+        if (draw) row_key[threadIdx.x] = mix64(seed ^ ((counter0 + r0 + threadIdx.x) * 0xD1342543DE82EF95ull));
+    }
     __syncthreads();
     const int n = nr * in;
+    // element e = (row rl, column j); a step of 256 elements moves both without a division
+    const int step_r = 256 / in, step_j = 256 % in;
+    int rl = (int)threadIdx.x / in, j = (int)threadIdx.x % in;
     for (int e = threadIdx.x; e < n; e += 256) {
-        const int rl = e / in, j = e - rl * in;
         const uint64_t r = r0 + rl;
         const uint64_t src = perm ? perm[r] : r;
         float v = x[src * in + j];
         bool drop = false;
         if (keep) drop = keep[r * in + j] == 0;
-        else if (dropout > 0.0f) drop = uniform01(seed, counter0 + r, (uint64_t)j) < dropout;
+        else if (draw)  // uniform01(seed, counter0 + r, j) < dropout
+            drop = (float)(mix64(row_key[rl] + (uint64_t)j) >> 40) * (1.0f / 16777216.0f) < dropout;
         if (drop) v = 0.0f;
         if (v != 0.0f) nz[rl] = 1;  // benign race: every writer stores the same value
         xd[r * ldx + j] = v;
+        rl += step_r; j += step_j;
+        if (j >= in) { j -= in; ++rl; }
     }
     // column `in` is 1 (it multiplies the bias gradient row of dW1), the rest of the padding 0
     const int npad = ldx - in;
@@ -152,6 +162,42 @@ __global__ __launch_bounds__(256) void prep_rows_kernel(const float* __restrict_
     }
     __syncthreads();
     if ((int)threadIdx.x < nr) live[r0 + threadIdx.x] = (nz[threadIdx.x] || !skip_zero) ? 1 : 0;
+}
+
+// The same for rows of a multiple of four inputs that are padded to 64 floats: one thread per group of
+// four columns, a row per 16 consecutive lanes, so that every access is 16 bytes wide, rows are written
+// whole and the "any nonzero" flag of a row is 16 bits of a ballot.
+__global__ __launch_bounds__(256) void prep_rows4_kernel(const float* __restrict__ x, const uint32_t* __restrict__ perm,
+                                                         const uint8_t* __restrict__ keep, float dropout, uint64_t seed,
+                                                         uint64_t counter0, uint64_t rows, int in, int skip_zero,
+                                                         float* __restrict__ xd, uint8_t* __restrict__ live)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint64_t r = t >> 4;
+    const int j = 4 * (int)(t & 15);
+    const bool in_row = r < rows;
+    float4 v = make_float4(j == in ? 1.0f : 0.0f, 0.0f, 0.0f, 0.0f);  // column `in` is 1, the rest of the padding 0
+    if (in_row && j < in) {
+        const uint64_t src = perm ? perm[r] : r;
+        v = *reinterpret_cast<const float4*>(x + src * in + j);
+        float* e = &v.x;
+        if (keep) {
+            const uint32_t k4 = *reinterpret_cast<const uint32_t*>(keep + r * in + j);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (((k4 >> (8 * q)) & 0xffu) == 0) e[q] = 0.0f;
+        } else if (dropout > 0.0f) {
+            const uint64_t key = mix64(seed ^ ((counter0 + r) * 0xD1342543DE82EF95ull));  // uniform01(seed, counter0 + r, j + q)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if ((float)(mix64(key + (uint64_t)(j + q)) >> 40) * (1.0f / 16777216.0f) < dropout) e[q] = 0.0f;
+        }
+    }
+    const bool nonzero = in_row && j < in && (v.x != 0.0f || v.y != 0.0f || v.z != 0.0f || v.w != 0.0f);
+    const unsigned long long any = __ballot(nonzero);
+    if (!in_row) return;
+    *reinterpret_cast<float4*>(xd + r * 64 + j) = v;
+    if (j == 0) live[r] = (((any >> (threadIdx.x & 48)) & 0xffffull) || !skip_zero) ? 1 : 0;
 }
 
 // ---- softmax, loss, output delta -----------------------------------------------------
@@ -1761,10 +1807,16 @@ int net_accumulate(Net* n, const AccumArgs& a, hipStream_t s)
         // gather / dropout / live flags
         {
             ProfScope prof("prep", s);
-            hipLaunchKernelGGL(prep_rows_kernel, dim3((unsigned)((R + kPrepRows - 1) / kPrepRows)), dim3(256), 0, s,
-                           a.perm_dev ? a.x_dev : a.x_dev + r0 * n->in, a.perm_dev ? a.perm_dev + r0 : nullptr,
-                           a.keep_dev ? a.keep_dev + r0 * n->in : nullptr, a.dropout, a.seed, a.row_counter0 + r0, R,
-                           (int)n->in, a.skip_zero_rows ? 1 : 0, w.xd, w.ldx, w.live);
+            const float* xs = a.perm_dev ? a.x_dev : a.x_dev + r0 * n->in;
+            const uint8_t* ks = a.keep_dev ? a.keep_dev + r0 * n->in : nullptr;
+            if (n->in % 4 == 0 && w.ldx == 64 && ((uintptr_t)xs & 15) == 0 && ((uintptr_t)ks & 3) == 0)
+                hipLaunchKernelGGL(prep_rows4_kernel, dim3((unsigned)((R * 16 + 255) / 256)), dim3(256), 0, s, xs,
+                                   a.perm_dev ? a.perm_dev + r0 : nullptr, ks, a.dropout, a.seed, a.row_counter0 + r0, R,
+                                   (int)n->in, a.skip_zero_rows ? 1 : 0, w.xd, w.live);
+            else
+                hipLaunchKernelGGL(prep_rows_kernel, dim3((unsigned)((R + kPrepRows - 1) / kPrepRows)), dim3(256), 0, s, xs,
+                                   a.perm_dev ? a.perm_dev + r0 : nullptr, ks, a.dropout, a.seed, a.row_counter0 + r0, R,
+                                   (int)n->in, a.skip_zero_rows ? 1 : 0, w.xd, w.ldx, w.live);
         }
         SZ_HIP(hipGetLastError());
         // the ReLU derivative travels as one bit per unit
