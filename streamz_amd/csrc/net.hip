@@ -610,6 +610,19 @@ __device__ __forceinline__ float row16_sum(float x)
     return x + dpp_read<0x140>(x);
 }
 
+// Column sums of a 16 x 16 block held as float4 o = block[row m][4 g + 0..3] (m = lane & 15): a
+// butterfly over the four lanes of a quad.  With its xor-1 partner a lane trades two of the four
+// columns, with its xor-2 partner one of the two left, and ends with the sum over the quad's four rows
+// of column 4 g + quad_col(m), quad_col = {0, 2, 1, 3}[m & 3].
+__device__ __forceinline__ int quad_col(int m) { return ((m & 1) << 1) | ((m & 2) >> 1); }
+__device__ __forceinline__ float quad_colsum(const float4& o, bool odd, bool hi)
+{
+    const float k0 = odd ? o.z : o.x, k1 = odd ? o.w : o.y;
+    const float a0 = k0 + dpp_read<0xB1>(odd ? o.x : o.z);
+    const float a1 = k1 + dpp_read<0xB1>(odd ? o.y : o.w);
+    return (hi ? a1 : a0) + dpp_read<0x4E>(hi ? a0 : a1);
+}
+
 #define SZ_MFMA16(a_, b_, c_) __builtin_amdgcn_mfma_f32_16x16x4f32((a_), (b_), (c_), 0, 0, 0)
 
 // ---- inference head: logits, softmax, per-window vote in one pass ------------------------
@@ -777,7 +790,8 @@ __global__ __launch_bounds__(256, 2) void head_mfma_kernel(HeadArgs a)
 #pragma unroll
     for (int q = 0; q < 4; ++q) ident[q] = (4 * g + q == m) ? 1.0f : 0.0f;
     f32x4 acc3[KB];
-    float accb2[KB];  // db2[16j + m], rows of group g only
+    float accb2[KB];  // db2[16 j + 4 g + quad_col(m)], rows of the lane's quad only
+    const bool odd = (m & 1) != 0, hi = (m & 2) != 0;
 #pragma unroll
     for (int j = 0; j < KB; ++j) {
         accb2[j] = 0.0f;
@@ -890,13 +904,7 @@ __global__ __launch_bounds__(256, 2) void head_mfma_kernel(HeadArgs a)
             for (int v = 0; v < 4; ++v) acc3[j] = SZ_MFMA16(hb[v], d3[v], acc3[j]);
             const float4 o = make_float4(q[0] * (1.0f - h.x * h.x), q[1] * (1.0f - h.y * h.y),
                                          q[2] * (1.0f - h.z * h.z), q[3] * (1.0f - h.w * h.w));
-            // row sums for db2 (lib.rs:1038): the identity product moves the block to [row 4g+v][k = m]
-            f32x4 ot = {0.f, 0.f, 0.f, 0.f};
-            ot = SZ_MFMA16(o.x, ident[0], ot);
-            ot = SZ_MFMA16(o.y, ident[1], ot);
-            ot = SZ_MFMA16(o.z, ident[2], ot);
-            ot = SZ_MFMA16(o.w, ident[3], ot);
-            accb2[j] += (ot[0] + ot[1]) + (ot[2] + ot[3]);
+            accb2[j] += quad_colsum(o, odd, hi);  // db2 (lib.rs:1038)
             if (okm) *reinterpret_cast<float4*>(a.d2 + rm * H2 + 16 * j + 4 * g) = o;
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -921,9 +929,9 @@ __global__ __launch_bounds__(256, 2) void head_mfma_kernel(HeadArgs a)
     if (a.add && tid == 0) { st_prev[0] = a.stats[2 * (size_t)blockIdx.x]; st_prev[1] = a.stats[2 * (size_t)blockIdx.x + 1]; }
     // sums over the rows held by different lane groups
 #pragma unroll
-    for (int j = 0; j < KB; ++j) {
-        accb2[j] += __shfl_xor(accb2[j], 16);
-        accb2[j] += __shfl_xor(accb2[j], 32);
+    for (int j = 0; j < KB; ++j) {  // over the four quads of a row of 16 lanes
+        accb2[j] += __shfl_xor(accb2[j], 4);
+        accb2[j] += __shfl_xor(accb2[j], 8);
     }
     accb3 += __shfl_xor(accb3, 16);
     accb3 += __shfl_xor(accb3, 32);
@@ -945,11 +953,11 @@ __global__ __launch_bounds__(256, 2) void head_mfma_kernel(HeadArgs a)
 #pragma unroll
             for (int v = 0; v < 4; ++v) RW[(4 * j + v) * 64 + lane] = acc3[j][v];
     }
-    if (g == 0) {
+    if (m < 4) {
 #pragma unroll
-        for (int j = 0; j < KB; ++j) redb[wave][16 * j + m] = accb2[j];
-        redb[wave][H2 + m] = accb3;
+        for (int j = 0; j < KB; ++j) redb[wave][16 * j + 4 * g + quad_col(m)] = accb2[j];
     }
+    if (g == 0) redb[wave][H2 + m] = accb3;
     __syncthreads();
     if (wave >= 2) {
 #pragma unroll
@@ -1010,7 +1018,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void head_wide_kernel(HeadArgs a)
     f32x4 ident;
 #pragma unroll
     for (int q = 0; q < 4; ++q) ident[q] = (4 * g + q == m) ? 1.0f : 0.0f;
-    float accb2[KB], accb3[NCB];
+    float accb2[KB], accb3[NCB];  // accb2: db2[16 j + 4 g + quad_col(m)], rows of the lane's quad only
+    const bool odd = (m & 1) != 0, hi = (m & 2) != 0;
 #pragma unroll
     for (int j = 0; j < KB; ++j) accb2[j] = 0.0f;
 #pragma unroll
@@ -1123,12 +1132,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void head_wide_kernel(HeadArgs a)
             }
             const float4 o = make_float4(q[0] * (1.0f - h.x * h.x), q[1] * (1.0f - h.y * h.y),
                                          q[2] * (1.0f - h.z * h.z), q[3] * (1.0f - h.w * h.w));
-            f32x4 ot = {0.f, 0.f, 0.f, 0.f};
-            ot = SZ_MFMA16(o.x, ident[0], ot);
-            ot = SZ_MFMA16(o.y, ident[1], ot);
-            ot = SZ_MFMA16(o.z, ident[2], ot);
-            ot = SZ_MFMA16(o.w, ident[3], ot);
-            accb2[j] += (ot[0] + ot[1]) + (ot[2] + ot[3]);
+            accb2[j] += quad_colsum(o, odd, hi);  // db2 (lib.rs:1038)
             if (okm) *reinterpret_cast<float4*>(a.d2 + rm * H2 + 16 * j + 4 * g) = o;
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -1144,9 +1148,9 @@ __global__ __launch_bounds__(64 * WAVES, 2) void head_wide_kernel(HeadArgs a)
     double st_prev[2] = {0.0, 0.0};
     if (a.add && tid == 0) { st_prev[0] = a.stats[2 * (size_t)blockIdx.x]; st_prev[1] = a.stats[2 * (size_t)blockIdx.x + 1]; }
 #pragma unroll
-    for (int j = 0; j < KB; ++j) {
-        accb2[j] += __shfl_xor(accb2[j], 16);
-        accb2[j] += __shfl_xor(accb2[j], 32);
+    for (int j = 0; j < KB; ++j) {  // over the four quads of a row of 16 lanes
+        accb2[j] += __shfl_xor(accb2[j], 4);
+        accb2[j] += __shfl_xor(accb2[j], 8);
     }
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb) {
@@ -1163,9 +1167,11 @@ __global__ __launch_bounds__(64 * WAVES, 2) void head_wide_kernel(HeadArgs a)
     __syncthreads();  // the w3 images are no longer needed; their LDS now holds the per-wave sums
     float* red = wtab;  // [WAVES][H2 + 16 NCB]
     constexpr int RW = H2 + 16 * NCB;
-    if (g == 0) {
+    if (m < 4) {
 #pragma unroll
-        for (int j = 0; j < KB; ++j) red[wave * RW + 16 * j + m] = accb2[j];
+        for (int j = 0; j < KB; ++j) red[wave * RW + 16 * j + 4 * g + quad_col(m)] = accb2[j];
+    }
+    if (g == 0) {
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb) red[wave * RW + H2 + 16 * cb + m] = accb3[cb];
     }
