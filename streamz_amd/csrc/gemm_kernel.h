@@ -141,7 +141,7 @@ __device__ __forceinline__ void fetch_krows(const float* base, int ld, int c0, i
 }
 // PAIR: k row k goes to LDS row 2 (k % (KT/2)) + k / (KT/2), so that rows k and k + KT/2, which
 // one MFMA step multiplies, are neighbours.
-template <int TR, int KT, int PAIR = 0>
+template <int TR, int KT, int PAIR = 0, int LD = LDT>
 __device__ __forceinline__ void stash_krows(float* S, const Frag4 (&f)[TR * KT / 1024])
 {
 #pragma unroll
@@ -151,7 +151,7 @@ __device__ __forceinline__ void stash_krows(float* S, const Frag4 (&f)[TR * KT /
         q.x = f[i].v[0]; q.y = f[i].v[1]; q.z = f[i].v[2]; q.w = f[i].v[3];
         const int k = idx / (TR / 4);
         const int row = PAIR ? 2 * (k % (KT / 2)) + k / (KT / 2) : k;
-        *reinterpret_cast<float4*>(S + row * LDT + 4 * (idx % (TR / 4))) = q;
+        *reinterpret_cast<float4*>(S + row * LD + 4 * (idx % (TR / 4))) = q;
     }
 }
 
@@ -286,23 +286,28 @@ __device__ __forceinline__ void finish_tile(const GemmArgs& g, float* C, f32x16 
 }
 
 // TAG only separates instantiations, so that each call site is its own kernel in a profile.
-// TM = rows of the block tile, KT = K tile (16 or 32), DB = double-buffered LDS tiles.
-template <int AM, int BMd, int EPI, int TAG, int TM, int KT, int DB>
+// TM = rows of the block tile, KT = K tile (16 or 32), DB = double-buffered LDS tiles, BNT = columns
+// of the block tile (128; 256 for a k-major B under a 64-row tile: twice the matrix work between the
+// two barriers of a K tile).
+template <int AM, int BMd, int EPI, int TAG, int TM, int KT, int DB, int BNT = BN>
 __global__ __launch_bounds__(kGemmThreads) void gemm_kernel(GemmArgs g)
 {
+    static_assert(BNT == BN || (BNT == 2 * BN && BMd == B_KROWS && TM == 64), "wide tiles: k-major B, 64 rows");
     constexpr int BK = KT;
     constexpr int WAVES_M = TM / 64, WAVES_N = 4 / WAVES_M;
-    constexpr int WN = BN / WAVES_N;  // columns per wave: 64 or 32
+    constexpr int WN = BNT / WAVES_N;  // columns per wave: 64 or 32
     constexpr int TN = WN / 32;       // 32-wide MFMA tiles per wave along N
+    constexpr int LDTB = BNT + 4;     // row stride of a k-major B tile
     constexpr int LDA = AM == A_ROWS ? BK + 4 : LDT;  // A_ROWS: row-major tile [TM][BK + 4]
-    constexpr int LDB = BMd == B_ROWS ? LDR : LDT;
+    constexpr int LDB = BMd == B_ROWS ? LDR : LDTB;
     constexpr int HS = BK / 2;                        // MFMA steps per K tile
     constexpr int A_TILE = AM == A_ROWS ? TM * LDA : BK * LDT;
+    constexpr int B_TILE = BK * LDTB;
     __shared__ __attribute__((aligned(16))) float As_[(DB ? 2 : 1) * A_TILE];
-    __shared__ __attribute__((aligned(16))) float Bs_[(DB ? 2 : 1) * BK * LDT];
+    __shared__ __attribute__((aligned(16))) float Bs_[(DB ? 2 : 1) * B_TILE];
     int bx, by, bz;
     xcd_tile(bx, by, bz);
-    const int m0 = by * TM, n0 = bx * BN;
+    const int m0 = by * TM, n0 = bx * BNT;
     const int k_begin = bz * g.k_chunk;
     const int k_end = min(g.K, k_begin + g.k_chunk);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -335,10 +340,10 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_kernel(GemmArgs g)
             }
     }
 
-    Frag4 fa[TM * BK / 1024], fb[BN * BK / 1024];
+    Frag4 fa[TM * BK / 1024], fb[BNT * BK / 1024];
     // interior tiles (the common case) take straight-line 16-byte loads; edge tiles are guarded
     const bool a_inside = g.a_vec && g.ones_row < 0 && (m0 + TM <= g.M || (AM == A_KROWS && g.a_pad));
-    const bool b_inside = g.b_vec && n0 + BN <= g.N;
+    const bool b_inside = g.b_vec && n0 + BNT <= g.N;
     auto fetch = [&](int k0) {
         const bool k_inside = k0 + BK <= k_end;
         if (a_inside && (k_inside || (AM == A_ROWS && g.a_pad))) {
@@ -349,18 +354,18 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_kernel(GemmArgs g)
             else fetch_krows<TM, BK>(g.A, g.lda, m0, a_cols, k0, k_end, g.a_vec, g.ones_row, fa);
         }
         if (b_inside && k_inside) {
-            if (BMd == B_ROWS) fetch_rows_fast<BN, BK>(g.B, g.ldb, n0, k0, fb);
-            else fetch_krows_fast<BN, BK>(g.B, g.ldb, n0, k0, fb);
+            if (BMd == B_ROWS) fetch_rows_fast<BNT, BK>(g.B, g.ldb, n0, k0, fb);
+            else fetch_krows_fast<BNT, BK>(g.B, g.ldb, n0, k0, fb);
         } else {
-            if (BMd == B_ROWS) fetch_rows<BN, BK>(g.B, g.ldb, n0, g.N, k0, k_end, g.b_vec, fb);
-            else fetch_krows<BN, BK>(g.B, g.ldb, n0, g.N, k0, k_end, g.b_vec, -1, fb);
+            if (BMd == B_ROWS) fetch_rows<BNT, BK>(g.B, g.ldb, n0, g.N, k0, k_end, g.b_vec, fb);
+            else fetch_krows<BNT, BK>(g.B, g.ldb, n0, g.N, k0, k_end, g.b_vec, -1, fb);
         }
     };
     auto stash = [&](int buf) {
         float* As = As_ + buf * A_TILE;
-        float* Bs = Bs_ + buf * BK * LDT;
+        float* Bs = Bs_ + buf * B_TILE;
         if (AM == A_ROWS) stash_rows_rowmajor<TM, BK>(As, fa); else stash_krows<TM, BK>(As, fa);
-        if (BMd == B_ROWS) stash_rows<BN, BK, AM == A_ROWS>(Bs, fb); else stash_krows<BN, BK, AM == A_ROWS>(Bs, fb);
+        if (BMd == B_ROWS) stash_rows<BNT, BK, AM == A_ROWS>(Bs, fb); else stash_krows<BNT, BK, AM == A_ROWS, LDTB>(Bs, fb);
     };
     if (k_begin < k_end) fetch(k_begin);
     if (DB && k_begin < k_end) { stash(0); __syncthreads(); }
@@ -373,7 +378,7 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_kernel(GemmArgs g)
         }
         if (k0 + BK < k_end) fetch(k0 + BK);
         const float* As = As_ + buf * A_TILE;
-        const float* Bs = Bs_ + buf * BK * LDT;
+        const float* Bs = Bs_ + buf * B_TILE;
         // A_ROWS: step s multiplies k = s (lanes 0-31) and k = s + HS (lanes 32-63); otherwise
         // k = 2 s and 2 s + 1.  The fragments of the next step are read from LDS while the MFMAs
         // of this one run.

@@ -42,7 +42,12 @@ int launch_gemm(GemmArgs g, int splits, hipStream_t s)
     ProfScope prof(kGemmTagName[TAG], s);
     // 64-row tiles when 128-row tiles would leave compute units without a workgroup
     const long tiles128 = (long)((g.N + BN - 1) / BN) * ((g.M + BM - 1) / BM) * splits;
-    if (g.M <= 64 || (splits == 1 && tiles128 < 256)) {
+    if (g.M <= 64 && BMd == B_KROWS && g.N % (2 * BN) == 0 && (long)(g.N / (2 * BN)) * splits >= 256) {
+        // one 64-row tile of rows and a k-major B: 256-column tiles (dW1)
+        constexpr int BNW = BMd == B_KROWS ? 2 * BN : BN;
+        dim3 grid(g.N / (2 * BN), 1, splits);
+        hipLaunchKernelGGL((gemm_kernel<AM, BMd, EPI, TAG, 64, kGemmKT, kGemmDB, BNW>), grid, dim3(kGemmThreads), 0, s, g);
+    } else if (g.M <= 64 || (splits == 1 && tiles128 < 256)) {
         dim3 grid((g.N + BN - 1) / BN, (g.M + 63) / 64, splits);
         hipLaunchKernelGGL((gemm_kernel<AM, BMd, EPI, TAG, 64, kGemmKT, kGemmDB>), grid, dim3(kGemmThreads), 0, s, g);
     } else {
