@@ -12,7 +12,7 @@ import sys
 
 GEMM_TAGS = ["fwd1", "fwd2", "fwd3", "delta2", "delta1", "dw3", "dw2", "dw1"]
 OTHER = {"prep_rows_kernel": "prep", "head_mfma_kernel": "head", "head_wide_kernel": "head", "head_kernel": "head",
-         "slab_reduce_kernel": "reduce", "transpose_kernel": "w2t", "apply_kernel": "apply", "split_planes_kernel": "w2split"}
+         "slab_reduce_kernel": "reduce", "transpose_kernel": "w2t", "apply_kernel": "apply", "split_planes_kernel": "w2split", "prep_rows4_kernel": "prep"}
 
 
 def tag_of(name):
