@@ -89,16 +89,16 @@ int launch_gemm_x3(GemmArgs g, int splits, hipStream_t s)
 
 // The f32 products with a row-major first operand on 256 x 256 tiles walked by one workgroup per CU
 // (gemm_f32w_kernel): B as [N][K].
-template <int EPI, int TAG>
-int launch_gemm_f32w(GemmArgs g, hipStream_t s)
+template <int EPI, int TAG, int SRC = X3_ROWS_F32>
+int launch_gemm_f32w(GemmArgs g, hipStream_t s, int splits = 1)
 {
     if (g.M <= 0 || g.N <= 0) return SZH_OK;
-    if (int rc = allow_dynamic_lds((const void*)gemm_f32w_kernel<X3_ROWS_F32, X3_ROWS_F32, EPI, TAG>, FW_LDS_BYTES)) return rc;
+    if (int rc = allow_dynamic_lds((const void*)gemm_f32w_kernel<SRC, SRC, EPI, TAG>, FW_LDS_BYTES)) return rc;
     ProfScope prof(kGemmTagName[TAG], s);
-    g.tiles_x = (g.N + XW_TN - 1) / XW_TN; g.tiles_y = (g.M + XW_TM - 1) / XW_TM; g.tiles_z = 1;
-    const int tiles = g.tiles_x * g.tiles_y;
+    g.tiles_x = (g.N + XW_TN - 1) / XW_TN; g.tiles_y = (g.M + XW_TM - 1) / XW_TM; g.tiles_z = splits;
+    const int tiles = g.tiles_x * g.tiles_y * g.tiles_z;
     const int blocks = std::min((tiles + 7) / 8 * 8, compute_units() / 8 * 8);
-    hipLaunchKernelGGL((gemm_f32w_kernel<X3_ROWS_F32, X3_ROWS_F32, EPI, TAG>), dim3(blocks), dim3(XW_THREADS), FW_LDS_BYTES, s, g);
+    hipLaunchKernelGGL((gemm_f32w_kernel<SRC, SRC, EPI, TAG>), dim3(blocks), dim3(XW_THREADS), FW_LDS_BYTES, s, g);
     SZ_HIP(hipGetLastError());
     return SZH_OK;
 }
@@ -1548,6 +1548,18 @@ int grad_gemm_x3(const float* A, int lda, const float* B, int ldb, int M, int N,
     return launch_gemm_x3<X3_KROWS_F32, X3_KROWS_F32, EPI_SLAB, TAG>(g, (int)((rows + sp.k_chunk - 1) / sp.k_chunk), s);
 }
 
+// ... and on the f32 walking kernel (same conditions)
+template <int TAG>
+int grad_gemm_f32w(const float* A, int lda, const float* B, int ldb, int M, int N, uint64_t rows, float* slab,
+                   const SplitPlan& sp, bool add, hipStream_t s)
+{
+    GemmArgs g{};
+    g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = slab; g.ldc = N;
+    g.M = M; g.N = N; g.K = (int)rows; g.k_chunk = sp.k_chunk;
+    g.slab_add = add ? 1 : 0;
+    return launch_gemm_f32w<EPI_SLAB, TAG, X3_KROWS_F32>(g, s, (int)((rows + sp.k_chunk - 1) / sp.k_chunk));
+}
+
 int reduce_slabs(const float* slab, int splits, uint64_t len, float* grad, hipStream_t s)
 {
     ProfScope prof("reduce", s);
@@ -1786,7 +1798,7 @@ int net_accumulate(Net* n, const AccumArgs& a, hipStream_t s)
     const uint64_t rows0 = std::min<uint64_t>(chunk, a.rows);
     const SplitPlan sp = plan_splits(rows0, (int)kMaxSplits);
     const SplitPlan sp1 = plan_splits(rows0, (int)kMaxSplitsW1);
-    const SplitPlan sp2 = x3 ? plan_splits(rows0, (int)w2_split_cap(n)) : sp;  // dW2
+    const SplitPlan sp2 = (x3 || wide) ? plan_splits(rows0, (int)w2_split_cap(n)) : sp;  // dW2
     // the output layer: matrix-core head with dW3 in registers (<= 16 classes), matrix-core head
     // plus a GEMM for dW3 (<= 64 classes), vector head (<= 32 classes, other hidden2), or GEMMs
     const bool h2_tiles = n->h2 == 64 || n->h2 == 128 || n->h2 == 256;
@@ -1932,13 +1944,14 @@ int net_accumulate(Net* n, const AccumArgs& a, hipStream_t s)
         }
         if (rc) return rc;
         // weight gradients: contractions over the rows ([w1|b1] in one launch via the ones row)
-        if (x3 && R % 32) {  // zero rows up to the next multiple of 32
+        if ((x3 || wide) && R % 32) {  // zero rows up to the next multiple of 32
             const uint64_t pad = 32 - R % 32;
             SZ_HIP(hipMemsetAsync(w.h1 + R * n->h1, 0, pad * n->h1 * sizeof(float), s));
             SZ_HIP(hipMemsetAsync(w.d2 + R * n->h2, 0, pad * n->h2 * sizeof(float), s));
         }
         rc = x3 ? grad_gemm_x3<T_DW2>(w.h1, n->h1, w.d2, n->h2, n->h1, n->h2, R, w.slab + w.sl_w2, sp2, add, s)
-                : grad_gemm<T_DW2>(w.h1, n->h1, w.d2, n->h2, n->h1, n->h2, R, w.slab + w.sl_w2, sp2, add, false, s);
+           : wide ? grad_gemm_f32w<T_DW2>(w.h1, n->h1, w.d2, n->h2, n->h1, n->h2, R, w.slab + w.sl_w2, sp2, add, s)
+                  : grad_gemm<T_DW2>(w.h1, n->h1, w.d2, n->h2, n->h1, n->h2, R, w.slab + w.sl_w2, sp2, add, false, s);
         if (rc) return rc;
         rc = grad_gemm<T_DW1>(w.xd, w.ldx, w.d1, n->h1, n->in + 1, n->h1, R, w.slab + w.sl_w1, sp1, add, false, s, true);
         if (rc) return rc;
