@@ -1491,7 +1491,7 @@ int forward_hidden(Net* n, const float* x, uint64_t rows, bool relu2, hipStream_
                  : launch_gemm<A_ROWS, B_KROWS, EPI_BIAS_TANH, T_FWD2>(g, 1, s);
 }
 
-int forward_logits(Net* n, uint64_t rows, float* out, hipStream_t s, bool x3 = false)
+int forward_logits(Net* n, uint64_t rows, float* out, hipStream_t s, bool x3 = false, bool wide = false)
 {
     Workspace& w = n->ws;
     const float* P = n->d_params;
@@ -1501,6 +1501,10 @@ int forward_logits(Net* n, uint64_t rows, float* out, hipStream_t s, bool x3 = f
     if (x3) {  // B as [classes][hidden2] planes
         g.B = (const float*)w.w3s; g.ldb = n->h2; g.b_plane = (uint64_t)n->h2 * n->out;
         return launch_gemm_x3<X3_ROWS_F32, X3_ROWS_SPLIT, EPI_BIAS, T_FWD3>(g, 1, s);
+    }
+    if (wide) {  // B as [classes][hidden2]: w.w3t, which the caller has filled
+        g.B = w.w3t; g.ldb = n->h2;
+        return launch_gemm_f32w<EPI_BIAS, T_FWD3>(g, s);
     }
     return launch_gemm<A_ROWS, B_KROWS, EPI_BIAS, T_FWD3>(g, 1, s);
 }
@@ -1551,12 +1555,13 @@ int grad_gemm_x3(const float* A, int lda, const float* B, int ldb, int M, int N,
 // ... and on the f32 walking kernel (same conditions)
 template <int TAG>
 int grad_gemm_f32w(const float* A, int lda, const float* B, int ldb, int M, int N, uint64_t rows, float* slab,
-                   const SplitPlan& sp, bool add, hipStream_t s)
+                   const SplitPlan& sp, bool add, hipStream_t s, uint64_t slab_stride = 0)
 {
     GemmArgs g{};
     g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = slab; g.ldc = N;
     g.M = M; g.N = N; g.K = (int)rows; g.k_chunk = sp.k_chunk;
     g.slab_add = add ? 1 : 0;
+    g.slab_stride = slab_stride;
     return launch_gemm_f32w<EPI_SLAB, TAG, X3_KROWS_F32>(g, s, (int)((rows + sp.k_chunk - 1) / sp.k_chunk));
 }
 
@@ -1890,7 +1895,13 @@ int net_accumulate(Net* n, const AccumArgs& a, hipStream_t s)
             }
         } else {
             const bool x3o = use_x3_out(n, a.rows);
-            rc = forward_logits(n, R, w.p, s, x3o);
+            const bool wide_o = wide && n->out % 256 == 0;  // the output layer's three products on the walking kernel too
+            if (wide_o && r0 == 0) {
+                hipLaunchKernelGGL(transpose_kernel, dim3((n->out + 31) / 32, (n->h2 + 31) / 32), dim3(256), 0, s,
+                                   P + n->off_w3(), (int)n->h2, (int)n->out, w.w3t);
+                SZ_HIP(hipGetLastError());
+            }
+            rc = forward_logits(n, R, w.p, s, x3o, wide_o);
             if (rc) return rc;
             {
                 ProfScope prof("softmax", s);
@@ -1914,6 +1925,18 @@ int net_accumulate(Net* n, const AccumArgs& a, hipStream_t s)
                 }
                 // [dW3 | db3] per K range: the matrix part from the GEMM, the bias row from column sums
                 rc = grad_gemm_x3<T_DW3>(w.h2, n->h2, w.p, n->out, n->h2, n->out, R, w.slab + w.sl_w3, sp, add, s, len3);
+                if (rc) return rc;
+                rc = colsum_slabs(w.p, n->out, R, w.slab + w.sl_w3 + (uint64_t)n->h2 * n->out, sp, add, s, len3);
+                if (rc) return rc;
+            } else if (wide_o) {  // B = w3 itself, [hidden2][classes]
+                rc = launch_gemm_f32w<EPI_MUL_DTANH, T_DELTA2>(g, s);
+                if (rc) return rc;
+                if (R % 32) {  // zero rows up to the next multiple of 32 for the k-major reads of dW3
+                    const uint64_t pad = 32 - R % 32;
+                    SZ_HIP(hipMemsetAsync(w.h2 + R * n->h2, 0, pad * n->h2 * sizeof(float), s));
+                    SZ_HIP(hipMemsetAsync(w.p + R * n->out, 0, pad * n->out * sizeof(float), s));
+                }
+                rc = grad_gemm_f32w<T_DW3>(w.h2, n->h2, w.p, n->out, n->h2, n->out, R, w.slab + w.sl_w3, sp, add, s, len3);
                 if (rc) return rc;
                 rc = colsum_slabs(w.p, n->out, R, w.slab + w.sl_w3 + (uint64_t)n->h2 * n->out, sp, add, s, len3);
                 if (rc) return rc;

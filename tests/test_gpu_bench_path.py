@@ -33,6 +33,22 @@ def _oracle_grad_threads(onet, x, labels, threads=16, pieces=None):
     return np.sum(gs, axis=0)
 
 
+def _entries_of_near_zero_units(x, params, dims, size, eps=1.5e-6):
+    """Mask over the flat gradient of the entries that one first-layer ReLU decision can move: column j of
+    dW1, db1[j] and row j of dW2 for every unit j that has a pre-activation within eps of zero on some row."""
+    w1, b1 = params[0].astype(np.float64), params[1].astype(np.float64)
+    near = np.zeros(dims[1], bool)
+    for r0 in range(0, len(x), 20000):
+        z = x[r0:r0 + 20000].astype(np.float64) @ w1 + b1
+        near |= (np.abs(z) < eps).any(axis=0)
+    loose = np.zeros(size, bool)
+    loose[:60 * dims[1]].reshape(60, dims[1])[:, near] = True
+    loose[60 * dims[1]:61 * dims[1]][near] = True
+    off_w2 = 61 * dims[1]
+    loose[off_w2:off_w2 + dims[1] * dims[2]].reshape(dims[1], dims[2])[near, :] = True
+    return loose
+
+
 @pytest.mark.parametrize("gemm", ["f32", "bf16x3"])
 @pytest.mark.parametrize("dims,n", [((60, 512, 256, 16), 5000), ((60, 512, 256, 64), 3000)])
 def test_accumulate_dev_with_seeded_dropout_matches_oracle(sz, po, dims, n, gemm):
@@ -108,6 +124,37 @@ def test_accumulate_dev_at_the_wide_configuration(sz, po, gemm):
     np.testing.assert_allclose(net.forward(x[:1280]), probs, atol=1e-4)
 
 
+def test_accumulate_dev_at_the_wide_configuration_on_the_walking_f32_kernel(sz, po):
+    """60-2048-2048-256 at 16 421 rows: enough 256 x 256 tiles that the f32 mode runs every large product,
+    the output layer's three included, on the walking kernel (ragged last tile, rows zeroed up to the next
+    multiple of 32 for the k-major reads).  Against the oracle's gradient and probabilities."""
+    import torch
+    rng = np.random.default_rng(47)
+    dims = (60, 2048, 2048, 256)
+    onet = po.Net(*dims)
+    params = [(rng.uniform(-0.5, 0.5, s) * (0.08 if len(s) == 2 and s[0] > 60 else 1.0)).astype(np.float32)
+              for s in onet.shapes()]
+    onet.set_params(params)
+    net = sz.SimpleNeuralNet(*dims, init=params)
+    n = 16421
+    x = rng.standard_normal((n, 60)).astype(np.float32)
+    labels = rng.integers(0, 256, n).astype(np.int32)
+    dx, dl = torch.from_numpy(x).cuda(), torch.from_numpy(labels).cuda()
+    s = torch.cuda.current_stream().cuda_stream
+    net.zero_grad_dev(s)
+    net.accumulate_dev(dx.data_ptr(), dl.data_ptr(), n, stream=s)
+    torch.cuda.synchronize()
+    g = grad_view(net).cpu().numpy()
+    want = _oracle_grad_threads(onet, x, labels, pieces=64)
+    scale = np.abs(want).max()
+    loose = _entries_of_near_zero_units(x, params, dims, want.size)
+    np.testing.assert_allclose(g[:-2][~loose], want[~loose], atol=3e-5 * scale)
+    np.testing.assert_allclose(g[:-2][loose], want[loose], atol=3e-4 * scale)
+    assert g[-1] == n
+    tail = slice(n - 300, n)
+    np.testing.assert_allclose(net.forward(x)[tail], onet.forward(x[tail]), atol=1e-4)
+
+
 def test_accumulate_dev_at_a_row_count_that_takes_the_walking_f32_kernel(sz, po):
     """From 512 tiles of 256 x 256 per product on (131 072 rows at 60-512-256-16) fwd1, fwd2 and delta1 run
     on the 256-tile walking kernel: 140 003 rows (a ragged last tile) against the oracle's gradient and
@@ -137,17 +184,8 @@ def test_accumulate_dev_at_a_row_count_that_takes_the_walking_f32_kernel(sz, po)
     # ReLU decision depends on how the 60-term sum was rounded (the oracle multiplies and adds, the
     # matrix instruction fuses).  Such a decision moves the unit's column of dW1, its db1 entry and its
     # row of dW2 by one row's contribution: those entries are compared at a looser bound.
-    w1, b1 = params[0].astype(np.float64), params[1].astype(np.float64)
-    near = np.zeros(dims[1], bool)
-    for r0 in range(0, n, 20000):
-        z = x[r0:r0 + 20000].astype(np.float64) @ w1 + b1
-        near |= (np.abs(z) < 1.5e-6).any(axis=0)
-    assert near.sum() < 64   # of 512 units
-    loose = np.zeros(want.size, bool)
-    loose[:60 * dims[1]].reshape(60, dims[1])[:, near] = True
-    loose[60 * dims[1]:61 * dims[1]][near] = True
-    off_w2 = 61 * dims[1]
-    loose[off_w2:off_w2 + dims[1] * dims[2]].reshape(dims[1], dims[2])[near, :] = True
+    loose = _entries_of_near_zero_units(x, params, dims, want.size)
+    assert loose[60 * dims[1]:61 * dims[1]].sum() < 64   # of 512 units
     np.testing.assert_allclose(g[:-2][~loose], want[~loose], atol=2e-5 * scale)
     np.testing.assert_allclose(g[:-2][loose], want[loose], atol=2e-4 * scale)
     assert g[-1] == n - 1
