@@ -32,6 +32,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 #include "internal.h"
 #include "prof.h"
@@ -68,6 +69,9 @@ struct StepArgs {
     float lr;
     float* part;             // [2][workgroups][h2][8] partial second-layer sums
     unsigned* flags;         // one arrival count per workgroup, zero at launch
+    unsigned* ticket;        // one-XCD launch: roles handed out in arrival order (zero at launch)
+    unsigned long long* acc; // one-XCD launch: [3][h2][8] fixed-point sums of the partial second layer (zero at launch)
+    int nb;                  // workgroups that take part (the grid itself in the ordinary launch)
     int* abort_flag;         // set when a workgroup gives up waiting (never in a healthy run)
     int force_abort;         // test hook: the last workgroup reports a time-out before its first step
     double* totals;          // {loss, live rows} of this call (zero at launch)
@@ -128,10 +132,29 @@ constexpr int kStepProfSlots = 16;
 // K-split products (logits, delta1), delta2, dW3 (the same rows of w3), b2 and dW2.  What one
 // phase writes there, only the same wave reads in the next, so those phases follow each other
 // without a workgroup barrier (a wavefront's LDS operations execute in program order).
-template <int H2T, int CWT, bool PROF>
+//
+// ONEX: every participating workgroup sits on the same XCD.  The grid is 8 x the participants;
+// workgroups that find themselves on another XCD leave at once, those on XCD 0 take their role
+// (which hidden-1 units they own) from a ticket counter.  CUs of one XCD share one L2, so the
+// exchange needs no write-through: plain stores land in that L2, flags are polled with atomics
+// that execute there, and one L1 invalidate per step makes the slot loads miss the CU's L1 and
+// hit the L2.
+template <int H2T, int CWT, bool PROF, bool ONEX>
 __global__ __launch_bounds__(kStepThreads) void step_kernel(StepArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float sm[];
+    __shared__ int role_s;
+    int role = (int)blockIdx.x;
+    if (ONEX) {
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(20, 0, 4)" : "=s"(xcc));  // XCC_ID
+        if (threadIdx.x == 0) atomicAdd(a.flags + 40 + (xcc & 15u), 1u);   // arrivals per XCD (diagnostic, unused flag words)
+        if (xcc != 0) return;
+        if (threadIdx.x == 0) role_s = (int)atomicAdd(a.ticket, 1u);
+        __syncthreads();
+        role = role_s;
+        if (role >= a.nb) return;
+    }
     // PROF: wall-clock ticks spent up to each mark, summed over the steps (uniform, scalar registers)
     unsigned long long pacc[kStepProfSlots] = {};
     unsigned long long pt0 = 0;
@@ -139,7 +162,8 @@ __global__ __launch_bounds__(kStepThreads) void step_kernel(StepArgs a)
     const int tid = threadIdx.x, lane = tid & 63, m16 = lane & 15, g4 = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     __builtin_assume(wave >= 0 && wave < kStepThreads / 64);
-    const int NB = gridDim.x, blk = blockIdx.x;
+    const int NB = ONEX ? a.nb : (int)gridDim.x, blk = role;
+    constexpr int kAux = ONEX ? 0 : 16;   // cache policy of the slot accesses: plain, or sc1
     constexpr int IN = kStepIn, HS = kStepHS, LDW1 = kStepLdW1, LDH1 = kStepLdH1, TPWMAX = 4;
     const int H2 = H2T ? H2T : a.h2;
     const int C = a.out;
@@ -245,6 +269,12 @@ __global__ __launch_bounds__(kStepThreads) void step_kernel(StepArgs a)
     const unsigned slot_bytes = kStepRows * (unsigned)H2 * 4u;
     __amdgpu_buffer_rsrc_t part_rs = __builtin_amdgcn_make_buffer_rsrc(a.part, 0, (int)(2u * (unsigned)NB * slot_bytes), 0x00020000);
 
+    // one-XCD launch: fixed-point sums, three arrays used in turn
+    constexpr float kFixClamp = 524287.0f;
+    constexpr double kFixBias = 1572864.0;   // 1.5 x 2^20: doubles in [2^20, 2^21) are 2^-32 apart
+    __amdgpu_buffer_rsrc_t acc_rs = __builtin_amdgcn_make_buffer_rsrc(a.acc, 0, ONEX ? 3 * H2 * kStepRows * 8 : 0, 0x00020000);
+    int acc_cur = 0;
+
     bool healthy = true;
     if (a.force_abort && blk == NB - 1) {
         if (tid == 0) __hip_atomic_store(a.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -309,31 +339,69 @@ __global__ __launch_bounds__(kStepThreads) void step_kernel(StepArgs a)
                 for (int u = 0; u < TPWMAX; ++u) acc[u] = SZ_MFMA16(a4[st >> 2][st & 3], w2f[u][st], acc[u]);
             SZ_SCHED_FENCE();
             // slot layout [column][8 rows]: lane (column m16, g4 < 2) stores rows 4 g4 .. 4 g4 + 3 as 16 bytes
+            if (ONEX) {
+                // One XCD: the workgroups add their partials into one array in the shared L2 with 64-bit
+                // integer atomics.  A partial x becomes the fixed-point number round(x 2^32), read off the
+                // mantissa of the double x + 1.5 2^20 (exact for |x| < 2^19, beyond which x is clamped);
+                // integer sums do not depend on the order of arrival, so every workgroup reads the same
+                // bits whatever the timing.  The constant's bits are taken off again by the reader.
+                unsigned long long* accb = a.acc + (size_t)acc_cur * H2 * kStepRows;
 #pragma unroll
-            for (int u = 0; u < TPWMAX; ++u)
-                if (g4 < 2 && u < ntw)
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[u]), part_rs,
-                                                           (buf * NB + blk) * slot_bytes + ((16 * tt[u] + m16) * kStepRows + 4 * g4) * 4u, 0, 16);
+                for (int u = 0; u < TPWMAX; ++u)
+                    if (g4 < 2 && u < ntw) {
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) {
+                            const double d = (double)fminf(fmaxf(acc[u][v], -kFixClamp), kFixClamp) + kFixBias;
+                            // element (tile, row 4 g4 + v, column m16) at ((tile 4 + v) 2 + g4) 16 + m16: one instruction covers 256 contiguous bytes
+                            __hip_atomic_fetch_add(accb + ((tt[u] * 4 + v) * 2 + g4) * 16 + m16, __builtin_bit_cast(unsigned long long, d),
+                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
+                    }
+            } else {
+#pragma unroll
+                for (int u = 0; u < TPWMAX; ++u)
+                    if (g4 < 2 && u < ntw)
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[u]), part_rs,
+                                                               (buf * NB + blk) * slot_bytes + ((16 * tt[u] + m16) * kStepRows + 4 * g4) * 4u, 0, kAux);
+            }
         }
         STEP_MARK(2);   // partial h2 computed and stored
         // 3. publish: every storing wave drains its write-through stores, then one lane raises the flag
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) {
-            __hip_atomic_store(&a.flags[blk], (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (ONEX) __hip_atomic_store(&a.flags[blk], (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            else __hip_atomic_store(&a.flags[blk], (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             ctl[16] = 1;
         }
         STEP_MARK(3);   // drain + flag
-        if (wave == 0 && lane < NB) {   // wave 0 waits for every workgroup's flag
-            const unsigned long long tw0 = wall_clock64();
-            while (__hip_atomic_load(&a.flags[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(step + 1)) {
-                __builtin_amdgcn_s_sleep(1);
-                if (wall_clock64() - tw0 > kStepTimeoutTicks || __hip_atomic_load(a.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                    __hip_atomic_store(a.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    ctl[16] = 0;
-                    break;
+        if (wave == 0) {   // wave 0 waits for every workgroup's flag
+            if (lane < NB) {
+                const unsigned long long tw0 = wall_clock64();
+                auto seen = [&]() -> unsigned {
+                    // ONEX: an atomic without device scope executes in the XCD's L2, where the others' stores are
+                    // (written as an instruction: the compiler turns an idempotent read-modify-write into a load that may hit L1)
+                    if (ONEX) {
+                        unsigned got;
+                        asm volatile("global_atomic_umax %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)"
+                                     : "=&v"(got) : "v"(&a.flags[lane]), "v"(0u) : "memory");
+                        return got;
+                    }
+                    return __hip_atomic_load(&a.flags[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                };
+                while (seen() < (unsigned)(step + 1)) {
+                    __builtin_amdgcn_s_sleep(1);
+                    const unsigned long long waited = wall_clock64() - tw0;
+                    if (waited < 2000ull) continue;   // the abort word is looked at after 20 us of waiting
+                    if (waited > kStepTimeoutTicks || __hip_atomic_load(a.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                        __hip_atomic_store(a.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ctl[16] = 0;
+                        break;
+                    }
                 }
             }
+            // ONEX: drop this CU's L1 so that the slot loads below (any wave, after the barrier) come from L2
+            if (ONEX) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // no instruction: keeps the slot loads below the poll
         __syncthreads();
@@ -344,6 +412,40 @@ __global__ __launch_bounds__(kStepThreads) void step_kernel(StepArgs a)
         // same in every workgroup).  A slot is 2 H2 pieces of 16 bytes: piece 2 c + h holds rows
         // 4 h .. 4 h + 3 of column c; in pass p a lane takes piece (lane & 31) of tile 2 p + lane / 32.
         // All loads are sc1 and issued before the first add.
+        if (ONEX) {
+            // the sums of this step: a lane takes elements 2 lane and 2 lane + 1 of each of its tiles (128 a tile): one row, two columns
+            u32x4 q[TPWMAX];
+#pragma unroll
+            for (int u = 0; u < TPWMAX; ++u)
+                q[u] = __builtin_amdgcn_raw_buffer_load_b128(acc_rs, (unsigned)((acc_cur * H2 * kStepRows + tt[u] * 128 + 2 * lane) * 8), 0, 0);
+            // the array of the step before last is read by nobody any more (every workgroup has announced
+            // this step, so it has finished the previous one): clear this workgroup's share for the next step
+            if (wave == 1) {
+                const int freed = acc_cur == 0 ? 2 : acc_cur - 1;
+                for (int c = blk; c < H2 * kStepRows * 8 / 1024; c += NB)
+                    __builtin_amdgcn_raw_buffer_store_b128(u32x4{0u, 0u, 0u, 0u}, acc_rs, (unsigned)(freed * H2 * kStepRows * 8 + c * 1024 + lane * 16), 0, 0);
+            }
+            // while those loads are in flight: the next step's values and the indices of the one after
+            SZ_SCHED_FENCE();
+            load_val(cur_val, idx, xv);
+            load_idx(cur_idx, idx);
+            advance(cur_val);
+            advance(cur_idx);
+            SZ_SCHED_FENCE();
+            const unsigned long long bias_bits = (unsigned long long)NB * __builtin_bit_cast(unsigned long long, (double)kFixBias);
+#pragma unroll
+            for (int u = 0; u < TPWMAX; ++u)
+                if (u < ntw) {
+                    const int col = 16 * tt[u] + ((2 * lane) & 15), row = 4 * ((lane >> 3) & 1) + (lane >> 4);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const unsigned long long bits = (unsigned long long)q[u][2 * i] | ((unsigned long long)q[u][2 * i + 1] << 32);
+                        const float sum = (float)((double)(long long)(bits - bias_bits) * (1.0 / 4294967296.0));
+                        h2s[row * LD2 + col + i] = step_tanh(b2s[col + i] + sum);
+                    }
+                }
+            acc_cur = acc_cur == 2 ? 0 : acc_cur + 1;
+        } else
         {
             f32x4 s[TPWMAX / 2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
             unsigned poff[TPWMAX / 2];
@@ -351,12 +453,27 @@ __global__ __launch_bounds__(kStepThreads) void step_kernel(StepArgs a)
             for (int p = 0; p < TPWMAX / 2; ++p) poff[p] = (unsigned)(32 * tt[2 * p + (lane >> 5)] + (lane & 31)) * 16u;
             for (int b0 = 0; b0 < NB; b0 += 16) {
                 u32x4 v[TPWMAX / 2][16];
+                // Every workgroup needs every slot; workgroup b asks for them in the order b, b + 1, ... so
+                // that the workgroups are not all at the same addresses at once.  The registers a slot
+                // lands in, and with them the order of the sum, are the same everywhere.
+                auto issue = [&](auto rot) {
+                    constexpr int R = decltype(rot)::value;
 #pragma unroll
-                for (int p = 0; p < TPWMAX / 2; ++p)
+                    for (int i = 0; i < 16; ++i) {
+                        constexpr int kMask = 15;
+                        const int b = (i + R) & kMask;
 #pragma unroll
-                    for (int b = 0; b < 16; ++b)
-                        if (2 * p < TPW)
-                            v[p][b] = __builtin_amdgcn_raw_buffer_load_b128(part_rs, (buf * NB + min(b0 + b, NB - 1)) * slot_bytes + poff[p], 0, 16);
+                        for (int p = 0; p < TPWMAX / 2; ++p)
+                            if (2 * p < TPW)
+                                v[p][b] = __builtin_amdgcn_raw_buffer_load_b128(part_rs, (buf * NB + min(b0 + b, NB - 1)) * slot_bytes + poff[p], 0, kAux);
+                    }
+                };
+                switch (blk & 15) {
+#define SZ_ROT(r_) case r_: issue(std::integral_constant<int, r_>{}); break;
+                    SZ_ROT(0) SZ_ROT(1) SZ_ROT(2) SZ_ROT(3) SZ_ROT(4) SZ_ROT(5) SZ_ROT(6) SZ_ROT(7)
+                    SZ_ROT(8) SZ_ROT(9) SZ_ROT(10) SZ_ROT(11) SZ_ROT(12) SZ_ROT(13) SZ_ROT(14) SZ_ROT(15)
+#undef SZ_ROT
+                }
                 if (b0 == 0) {
                     // while those loads are in flight: the next step's values and the indices of the one after
                     SZ_SCHED_FENCE();
@@ -666,13 +783,13 @@ int padded_classes(uint32_t out) { return ((int)out + 15) / 16 * 16; }
 size_t step_lds_bytes(int h2, int cw) { return (size_t)StepLds(h2, cw).total * sizeof(float) + 128; }
 
 typedef void (*StepFn)(StepArgs);
-template <bool PROF>
+template <bool PROF, bool ONEX>
 StepFn pick_step_kernel(int h2, int cw)
 {
-    if (h2 == 256 && cw == 16) return step_kernel<256, 16, PROF>;
-    if (h2 == 256 && cw == 32) return step_kernel<256, 32, PROF>;
-    if (h2 == 128 && cw == 16) return step_kernel<128, 16, PROF>;
-    return step_kernel<0, 0, PROF>;
+    if (h2 == 256 && cw == 16) return step_kernel<256, 16, PROF, ONEX>;
+    if (h2 == 256 && cw == 32) return step_kernel<256, 32, PROF, ONEX>;
+    if (h2 == 128 && cw == 16) return step_kernel<128, 16, PROF, ONEX>;
+    return step_kernel<0, 0, PROF, ONEX>;
 }
 
 }  // namespace
@@ -693,22 +810,21 @@ int net_pretrain_steps(Net* n, const float* d_win, uint32_t n_win, const uint32_
     static const int env_mode = [] { const char* v = std::getenv("STREAMZ_STEP_FORCE_ABORT"); return v ? std::atoi(v) : 0; }();
     // STREAMZ_STEP_PROF=1: the instrumented instantiation, per-phase times of workgroup 0 to stderr
     static const bool prof_on = [] { const char* v = std::getenv("STREAMZ_STEP_PROF"); return v && v[0] == '1'; }();
+    // STREAMZ_STEP_ONE_XCD=0: never place the workgroups on one XCD
+    static const bool one_xcd_on = [] { const char* v = std::getenv("STREAMZ_STEP_ONE_XCD"); return !(v && v[0] == '0'); }();
     const int nb = (int)(n->h1 / kStepHS);
     const int cw = padded_classes(n->out);
     const size_t lds = step_lds_bytes((int)n->h2, cw);
-    StepFn fn = prof_on ? pick_step_kernel<true>((int)n->h2, cw) : pick_step_kernel<false>((int)n->h2, cw);
-    SZ_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    // every workgroup must be resident at once: the exchange waits for all of them
-    int per_cu = 0, dev = 0, cus = 0;
+    int dev = 0, cus = 0;
     SZ_HIP(hipGetDevice(&dev));
     SZ_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    SZ_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)fn, kStepThreads, lds));
-    if ((long)per_cu * cus < nb) return SZH_STEP_NOT_RUN;
 
     // one allocation: [partial slots | shadow parameters | flags + abort word (zeroed)]
     const size_t part_bytes = (2ull * nb * kStepRows * n->h2 * sizeof(float) + 255) / 256 * 256;
     const size_t shadow_bytes = (n->param_count() * sizeof(float) + 255) / 256 * 256;
-    const size_t flag_bytes = 512;  // 64 flags, the abort word, at byte 384 the call's {loss, live rows}
+    // 64 flags, at byte 256 the abort word and the ticket counter, at byte 384 the call's {loss, live rows},
+    // from byte 512 the three fixed-point sum arrays of the one-XCD launch
+    const size_t flag_bytes = 512 + 3ull * n->h2 * kStepRows * sizeof(unsigned long long);
     char* base = nullptr;
     SZ_HIP(hipMalloc((void**)&base, part_bytes + shadow_bytes + flag_bytes));
     struct Free { char* p; ~Free() { (void)hipFree(p); } } guard{base};
@@ -721,23 +837,49 @@ int net_pretrain_steps(Net* n, const float* d_win, uint32_t n_win, const uint32_
     a.part = reinterpret_cast<float*>(base);
     a.flags = reinterpret_cast<unsigned*>(base + part_bytes + shadow_bytes);
     a.abort_flag = reinterpret_cast<int*>(a.flags + kStepMaxBlocks);
+    a.ticket = reinterpret_cast<unsigned*>(a.abort_flag + 1);
+    a.nb = nb;
+    a.acc = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(a.flags) + 512);
     a.force_abort = env_mode != 0 ? 1 : 0;
     a.totals = reinterpret_cast<double*>(reinterpret_cast<char*>(a.flags) + 384);
-    SZ_HIP(hipMemsetAsync(a.flags, 0, flag_bytes, s));
     unsigned long long* d_prof = nullptr;
     if (prof_on) { SZ_HIP(hipMalloc((void**)&d_prof, kStepProfSlots * sizeof(unsigned long long))); a.prof = d_prof; }
     struct FreeProf { unsigned long long* p; ~FreeProf() { if (p) (void)hipFree(p); } } guard2{d_prof};
-    {
-        ProfScope prof("steps", s);
-        hipLaunchKernelGGL(fn, dim3(nb), dim3(kStepThreads), lds, s, a);
-    }
-    SZ_HIP(hipGetLastError());
     struct { int abort; int pad[31]; double totals[2]; } tail;  // bytes 256 .. 400 of the flag block
     static_assert(sizeof(tail) == 144, "abort word at 256, totals at 384");
-    SZ_HIP(hipMemcpyAsync(&tail, a.abort_flag, sizeof(tail), hipMemcpyDeviceToHost, s));
-    SZ_HIP(hipStreamSynchronize(s));
-    const int abort_host = tail.abort;
-    if (d_prof) {
+
+    // First with all workgroups on one XCD (they must fit its CUs, one each), then spread over the chip.
+    // A launch that did not run every step leaves the parameters alone, so the next one starts afresh.
+    bool ran = false;
+    for (int onex = (one_xcd_on && nb <= cus / 8) ? 1 : 0; onex >= 0 && !ran; --onex) {
+        StepFn fn = prof_on ? (onex ? pick_step_kernel<true, true>((int)n->h2, cw) : pick_step_kernel<true, false>((int)n->h2, cw))
+                            : (onex ? pick_step_kernel<false, true>((int)n->h2, cw) : pick_step_kernel<false, false>((int)n->h2, cw));
+        SZ_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        // every workgroup must be resident at once: the exchange waits for all of them
+        int per_cu = 0;
+        SZ_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)fn, kStepThreads, lds));
+        if ((long)per_cu * cus < nb) return SZH_STEP_NOT_RUN;
+        SZ_HIP(hipMemsetAsync(a.flags, 0, flag_bytes, s));
+        {
+            ProfScope prof("steps", s);
+            hipLaunchKernelGGL(fn, dim3(onex ? 8 * nb : nb), dim3(kStepThreads), lds, s, a);
+        }
+        SZ_HIP(hipGetLastError());
+        SZ_HIP(hipMemcpyAsync(&tail, a.abort_flag, sizeof(tail), hipMemcpyDeviceToHost, s));
+        SZ_HIP(hipStreamSynchronize(s));
+        ran = tail.abort == 0;
+        if (onex && std::getenv("STREAMZ_STEP_DEBUG")) {
+            unsigned f[kStepMaxBlocks + 2] = {};
+            (void)hipMemcpy(f, a.flags, sizeof(f), hipMemcpyDeviceToHost);
+            std::fprintf(stderr, "one-XCD launch: abort %d, tickets %u, arrivals per XCD:", tail.abort, f[kStepMaxBlocks + 1]);
+            for (int i = 0; i < 16; ++i) std::fprintf(stderr, " %u", f[40 + i]);
+            std::fprintf(stderr, "; flags:");
+            for (int i = 0; i < nb; ++i) std::fprintf(stderr, " %u", f[i]);
+            std::fprintf(stderr, "\n");
+        }
+        if (!ran && a.force_abort) break;   // the test hook asks for the failure itself
+    }
+    if (d_prof && ran) {
         unsigned long long h[kStepProfSlots] = {};
         if (hipMemcpy(h, d_prof, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
             const uint64_t n_steps = (uint64_t)epochs * ((n_win + batch_size - 1) / batch_size);
@@ -746,7 +888,7 @@ int net_pretrain_steps(Net* n, const float* d_win, uint32_t n_win, const uint32_
             std::fprintf(stderr, "\n");
         }
     }
-    if (abort_host) {
+    if (!ran) {
         // some workgroup gave up waiting: nothing was adopted, the parameters are as before the call
         if (env_mode == 2) { set_error("training step kernel: a workgroup timed out waiting for the others; parameters unchanged"); return SZH_ENODEVICE; }
         return SZH_STEP_NOT_RUN;
