@@ -15,10 +15,13 @@
 //      softmax, loss, delta3, delta2                                      (lib.rs:1022-1034)
 //   6. delta1[:, own] = delta2 . w2[own, :]^T, then the updates of everything the workgroup
 //      owns or replicates, with the pre-update weights throughout        (lib.rs:1029-1059)
-// The exchange costs no cache-wide fence: the slots are written through to memory (sc1 stores),
-// every storing wave drains its stores, one lane raises the workgroup's flag (sc1), the readers
-// poll the flags and read the slots with sc1 loads only, which bypass their CU's L1.  Slots are
-// double-buffered, so one exchange per step is enough.  Every product runs on the 16x16x4 f32
+// The exchange costs no cache-wide fence.  When the workgroups fit one XCD (they share its L2) they
+// ADD their partials into one array there with 64-bit fixed-point atomics whose top bits count the
+// arrivals, so steps 3-5 are "add; read until complete" with no flag and no drain (see ONEX
+// below).  Otherwise the slots are written through to memory (sc1 stores), every storing wave
+// drains its stores, one lane raises the workgroup's flag (sc1), the readers poll the flags and
+// read the slots with sc1 loads only, which bypass their CU's L1; slots are double-buffered, so
+// one exchange per step is enough.  Every product runs on the 16x16x4 f32
 // matrix instruction with the 8 rows padded to a 16-row tile (padding rows are kept zero in LDS,
 // so no load is conditional).
 //
@@ -133,12 +136,12 @@ constexpr int kStepProfSlots = 16;
 // phase writes there, only the same wave reads in the next, so those phases follow each other
 // without a workgroup barrier (a wavefront's LDS operations execute in program order).
 //
-// ONEX: every participating workgroup sits on the same XCD.  The grid is 8 x the participants;
-// workgroups that find themselves on another XCD leave at once, those on XCD 0 take their role
-// (which hidden-1 units they own) from a ticket counter.  CUs of one XCD share one L2, so the
-// exchange needs no write-through: plain stores land in that L2, flags are polled with atomics
-// that execute there, and one L1 invalidate per step makes the slot loads miss the CU's L1 and
-// hit the L2.
+// ONEX: every participating workgroup sits on the same XCD.  The grid is 8 x the participants
+// (workgroups go to the 8 XCDs round-robin in launch order); workgroups that find themselves on
+// another XCD leave at once, those on XCD 0 take their role (which hidden-1 units they own) from a
+// ticket counter.  CUs of one XCD share one L2, where atomics without device scope execute: the
+// sum of the partials is formed there by integer atomics instead of every workgroup reading every
+// other's slot (16 KB read per workgroup and step instead of 128 KB at 16 workgroups).
 template <int H2T, int CWT, bool PROF, bool ONEX>
 __global__ __launch_bounds__(kStepThreads) void step_kernel(StepArgs a)
 {
@@ -205,7 +208,7 @@ __global__ __launch_bounds__(kStepThreads) void step_kernel(StepArgs a)
     for (int e = tid; e < 2 * kStepXs; e += kStepThreads) xsb[e] = 0.0f;
     for (int e = tid; e < 16 * LDH1; e += kStepThreads) h1s[e] = 0.0f;
     for (int e = tid; e < 4 * 16 * LDD3; e += kStepThreads) (sm + L.d3)[e] = 0.0f;
-    if (tid < 17) ctl[tid] = 0;
+    if (tid < 17) ctl[tid] = tid == 16 ? 1 : 0;
 
     const uint32_t steps_per_epoch = (a.n_win + a.bs - 1) / a.bs;
     const uint64_t n_steps = (uint64_t)a.epochs * steps_per_epoch;
@@ -272,6 +275,7 @@ __global__ __launch_bounds__(kStepThreads) void step_kernel(StepArgs a)
     // one-XCD launch: fixed-point sums, three arrays used in turn
     constexpr float kFixClamp = 524287.0f;
     constexpr double kFixBias = 1572864.0;   // 1.5 x 2^20: doubles in [2^20, 2^21) are 2^-32 apart
+    constexpr unsigned long long kFixMant = (1ull << 52) - 1, kFixOne = 1ull << 58;
     __amdgpu_buffer_rsrc_t acc_rs = __builtin_amdgcn_make_buffer_rsrc(a.acc, 0, ONEX ? 3 * H2 * kStepRows * 8 : 0, 0x00020000);
     int acc_cur = 0;
 
@@ -341,10 +345,12 @@ __global__ __launch_bounds__(kStepThreads) void step_kernel(StepArgs a)
             // slot layout [column][8 rows]: lane (column m16, g4 < 2) stores rows 4 g4 .. 4 g4 + 3 as 16 bytes
             if (ONEX) {
                 // One XCD: the workgroups add their partials into one array in the shared L2 with 64-bit
-                // integer atomics.  A partial x becomes the fixed-point number round(x 2^32), read off the
-                // mantissa of the double x + 1.5 2^20 (exact for |x| < 2^19, beyond which x is clamped);
+                // integer atomics.  A partial x becomes the fixed-point number round(x 2^32) + 2^51, read off
+                // the mantissa of the double x + 1.5 2^20 (exact for |x| < 2^19, beyond which x is clamped);
                 // integer sums do not depend on the order of arrival, so every workgroup reads the same
-                // bits whatever the timing.  The constant's bits are taken off again by the reader.
+                // bits whatever the timing.  Each addend also carries a 1 at bit 58: the top six bits of an
+                // element count the workgroups that have added to it (at most 32 addends below 2^52 never
+                // carry into them), so an element says itself when it is complete and no flag is needed.
                 unsigned long long* accb = a.acc + (size_t)acc_cur * H2 * kStepRows;
 #pragma unroll
                 for (int u = 0; u < TPWMAX; ++u)
@@ -353,7 +359,8 @@ __global__ __launch_bounds__(kStepThreads) void step_kernel(StepArgs a)
                         for (int v = 0; v < 4; ++v) {
                             const double d = (double)fminf(fmaxf(acc[u][v], -kFixClamp), kFixClamp) + kFixBias;
                             // element (tile, row 4 g4 + v, column m16) at ((tile 4 + v) 2 + g4) 16 + m16: one instruction covers 256 contiguous bytes
-                            __hip_atomic_fetch_add(accb + ((tt[u] * 4 + v) * 2 + g4) * 16 + m16, __builtin_bit_cast(unsigned long long, d),
+                            __hip_atomic_fetch_add(accb + ((tt[u] * 4 + v) * 2 + g4) * 16 + m16,
+                                                   (__builtin_bit_cast(unsigned long long, d) & kFixMant) + kFixOne,
                                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         }
                     }
@@ -366,73 +373,100 @@ __global__ __launch_bounds__(kStepThreads) void step_kernel(StepArgs a)
             }
         }
         STEP_MARK(2);   // partial h2 computed and stored
-        // 3. publish: every storing wave drains its write-through stores, then one lane raises the flag
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) {
-            if (ONEX) __hip_atomic_store(&a.flags[blk], (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            else __hip_atomic_store(&a.flags[blk], (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            ctl[16] = 1;
-        }
-        STEP_MARK(3);   // drain + flag
-        if (wave == 0) {   // wave 0 waits for every workgroup's flag
-            if (lane < NB) {
-                const unsigned long long tw0 = wall_clock64();
-                auto seen = [&]() -> unsigned {
-                    // ONEX: an atomic without device scope executes in the XCD's L2, where the others' stores are
-                    // (written as an instruction: the compiler turns an idempotent read-modify-write into a load that may hit L1)
-                    if (ONEX) {
-                        unsigned got;
-                        asm volatile("global_atomic_umax %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)"
-                                     : "=&v"(got) : "v"(&a.flags[lane]), "v"(0u) : "memory");
-                        return got;
-                    }
-                    return __hip_atomic_load(&a.flags[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                };
-                while (seen() < (unsigned)(step + 1)) {
-                    __builtin_amdgcn_s_sleep(1);
-                    const unsigned long long waited = wall_clock64() - tw0;
-                    if (waited < 2000ull) continue;   // the abort word is looked at after 20 us of waiting
-                    if (waited > kStepTimeoutTicks || __hip_atomic_load(a.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                        __hip_atomic_store(a.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        ctl[16] = 0;
-                        break;
+        if (!ONEX) {
+            // 3. publish: every storing wave drains its write-through stores, then one lane raises the flag
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                __hip_atomic_store(&a.flags[blk], (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ctl[16] = 1;
+            }
+            STEP_MARK(3);   // drain + flag
+            if (wave == 0) {   // wave 0 waits for every workgroup's flag
+                if (lane < NB) {
+                    const unsigned long long tw0 = wall_clock64();
+                    while (__hip_atomic_load(&a.flags[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(step + 1)) {
+                        __builtin_amdgcn_s_sleep(1);
+                        const unsigned long long waited = wall_clock64() - tw0;
+                        if (waited < 2000ull) continue;   // the abort word is looked at after 20 us of waiting
+                        if (waited > kStepTimeoutTicks || __hip_atomic_load(a.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                            __hip_atomic_store(a.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            ctl[16] = 0;
+                            break;
+                        }
                     }
                 }
             }
-            // ONEX: drop this CU's L1 so that the slot loads below (any wave, after the barrier) come from L2
-            if (ONEX) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // no instruction: keeps the slot loads below the poll
+            __syncthreads();
+            healthy = ctl[16] != 0;
+            if (!healthy) break;
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // no instruction: keeps the slot loads below the poll
-        __syncthreads();
-        healthy = ctl[16] != 0;
-        if (!healthy) break;
         STEP_MARK(4);   // flags seen
         // 4. h2 = tanh(b2 + sum of the partials) for the own columns, workgroups in index order (the
         // same in every workgroup).  A slot is 2 H2 pieces of 16 bytes: piece 2 c + h holds rows
         // 4 h .. 4 h + 3 of column c; in pass p a lane takes piece (lane & 31) of tile 2 p + lane / 32.
         // All loads are sc1 and issued before the first add.
         if (ONEX) {
-            // the sums of this step: a lane takes elements 2 lane and 2 lane + 1 of each of its tiles (128 a tile): one row, two columns
-            u32x4 q[TPWMAX];
-#pragma unroll
-            for (int u = 0; u < TPWMAX; ++u)
-                q[u] = __builtin_amdgcn_raw_buffer_load_b128(acc_rs, (unsigned)((acc_cur * H2 * kStepRows + tt[u] * 128 + 2 * lane) * 8), 0, 0);
-            // the array of the step before last is read by nobody any more (every workgroup has announced
-            // this step, so it has finished the previous one): clear this workgroup's share for the next step
-            if (wave == 1) {
-                const int freed = acc_cur == 0 ? 2 : acc_cur - 1;
-                for (int c = blk; c < H2 * kStepRows * 8 / 1024; c += NB)
-                    __builtin_amdgcn_raw_buffer_store_b128(u32x4{0u, 0u, 0u, 0u}, acc_rs, (unsigned)(freed * H2 * kStepRows * 8 + c * 1024 + lane * 16), 0, 0);
+            // The sums of this step: a lane takes elements 2 lane and 2 lane + 1 of each of its tiles (128 a
+            // tile): one row, two columns, with sc1 loads (they never hit the CU's L1).  Loads of an element
+            // that is still being added to slow those additions down, so at first only wave 0 looks, and
+            // only at its first tile; once that shows all NB arrivals the rest has as a rule arrived as
+            // well, and every wave reads its tiles, again until each element is complete.
+            auto gave_up = [&](unsigned long long since) -> bool {
+                const unsigned long long waited = wall_clock64() - since;
+                if (waited < 2000ull) return false;   // the abort word is looked at after 20 us of waiting
+                if (waited > kStepTimeoutTicks || __hip_atomic_load(a.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                    __hip_atomic_store(a.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ctl[16] = 0;   // looked at after the next workgroup barrier but one
+                    return true;
+                }
+                return false;
+            };
+            const unsigned long long tw0 = wall_clock64();
+            if (wave == 0) {
+                for (;;) {
+                    const u32x4 s1 = __builtin_amdgcn_raw_buffer_load_b128(acc_rs, (unsigned)((acc_cur * H2 * kStepRows + tt[0] * 128 + 2 * lane) * 8), 0, 16);
+                    const bool ok = (s1[1] >> 26) == (unsigned)NB && (s1[3] >> 26) == (unsigned)NB;
+                    if (__builtin_amdgcn_ballot_w64(!ok) == 0 || gave_up(tw0)) break;
+                }
             }
-            // while those loads are in flight: the next step's values and the indices of the one after
+            __syncthreads();
+            u32x4 q[TPWMAX];
+            auto attempt = [&]() {
+#pragma unroll
+                for (int u = 0; u < TPWMAX; ++u)
+                    q[u] = __builtin_amdgcn_raw_buffer_load_b128(acc_rs, (unsigned)((acc_cur * H2 * kStepRows + tt[u] * 128 + 2 * lane) * 8), 0, 16);
+            };
+            auto complete = [&]() -> bool {
+                bool full = true;
+#pragma unroll
+                for (int u = 0; u < TPWMAX; ++u)
+                    if (u < ntw) full = full && (q[u][1] >> 26) == (unsigned)NB && (q[u][3] >> 26) == (unsigned)NB;
+                return __builtin_amdgcn_ballot_w64(!full) == 0;
+            };
+            attempt();
+            // behind those loads: the next step's values and the indices of the one after
             SZ_SCHED_FENCE();
             load_val(cur_val, idx, xv);
             load_idx(cur_idx, idx);
             advance(cur_val);
             advance(cur_idx);
             SZ_SCHED_FENCE();
-            const unsigned long long bias_bits = (unsigned long long)NB * __builtin_bit_cast(unsigned long long, (double)kFixBias);
+            while (!complete() && !gave_up(tw0)) {
+                __builtin_amdgcn_s_sleep(1);
+                attempt();
+            }
+            // Complete sums mean that every workgroup has begun this step, so none reads the array of the
+            // previous step any more: this workgroup clears its share of it for the step after the next
+            // (the stores have landed by the barrier at the end of this step, which wave 1 reaches after
+            // waiting for them, and every workgroup's atomics of that later step follow such a barrier).
+            if (wave == 1) {
+                const int freed = acc_cur == 0 ? 2 : acc_cur - 1;
+                for (int c = blk; c < H2 * kStepRows * 8 / 1024; c += NB)
+                    __builtin_amdgcn_raw_buffer_store_b128(u32x4{0u, 0u, 0u, 0u}, acc_rs, (unsigned)(freed * H2 * kStepRows * 8 + c * 1024 + lane * 16), 0, 0);
+            }
+            const long long bias_sum = (long long)NB << 51;   // every addend is offset by 2^51
 #pragma unroll
             for (int u = 0; u < TPWMAX; ++u)
                 if (u < ntw) {
@@ -440,7 +474,7 @@ __global__ __launch_bounds__(kStepThreads) void step_kernel(StepArgs a)
 #pragma unroll
                     for (int i = 0; i < 2; ++i) {
                         const unsigned long long bits = (unsigned long long)q[u][2 * i] | ((unsigned long long)q[u][2 * i + 1] << 32);
-                        const float sum = (float)((double)(long long)(bits - bias_bits) * (1.0 / 4294967296.0));
+                        const float sum = (float)((double)((long long)(bits & (kFixOne - 1)) - bias_sum) * (1.0 / 4294967296.0));
                         h2s[row * LD2 + col + i] = step_tanh(b2s[col + i] + sum);
                     }
                 }
@@ -545,6 +579,10 @@ __global__ __launch_bounds__(kStepThreads) void step_kernel(StepArgs a)
             w2b[u] = *reinterpret_cast<const f32x4*>(W2s + (16 + m16) * LD2 + 16 * tt[u] + 4 * g4);
         }
         __syncthreads();
+        if (ONEX) {   // a wave that gave up waiting has said so before this barrier
+            healthy = ctl[16] != 0;
+            if (!healthy) break;
+        }
         STEP_MARK(6);   // logits
         // 6. every wave for itself: softmax, loss with the pre-update weights, delta3 = o - t
         // (lib.rs:611-615, 1028) -> its own copy of delta3.  Lane = (row, class); a row's classes sit
@@ -756,6 +794,7 @@ __global__ __launch_bounds__(kStepThreads) void step_kernel(StepArgs a)
         // the next step's rows (fetched during the exchange) -> the other LDS buffer
         stage_rows(cb_ ^ 1, xv);
         STEP_MARK(12);  // delta1 combine, w1, b1 updates, next rows staged
+        if (ONEX && wave == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
 
@@ -873,8 +912,6 @@ int net_pretrain_steps(Net* n, const float* d_win, uint32_t n_win, const uint32_
             (void)hipMemcpy(f, a.flags, sizeof(f), hipMemcpyDeviceToHost);
             std::fprintf(stderr, "one-XCD launch: abort %d, tickets %u, arrivals per XCD:", tail.abort, f[kStepMaxBlocks + 1]);
             for (int i = 0; i < 16; ++i) std::fprintf(stderr, " %u", f[40 + i]);
-            std::fprintf(stderr, "; flags:");
-            for (int i = 0; i < nb; ++i) std::fprintf(stderr, " %u", f[i]);
             std::fprintf(stderr, "\n");
         }
         if (!ran && a.force_abort) break;   // the test hook asks for the failure itself
