@@ -850,7 +850,7 @@ int net_pretrain_steps(Net* n, const float* d_win, uint32_t n_win, const uint32_
     // STREAMZ_STEP_PROF=1: the instrumented instantiation, per-phase times of workgroup 0 to stderr
     static const bool prof_on = [] { const char* v = std::getenv("STREAMZ_STEP_PROF"); return v && v[0] == '1'; }();
     // STREAMZ_STEP_ONE_XCD=0: never place the workgroups on one XCD
-    static const bool one_xcd_on = [] { const char* v = std::getenv("STREAMZ_STEP_ONE_XCD"); return !(v && v[0] == '0'); }();
+    const bool one_xcd_on = [] { const char* v = std::getenv("STREAMZ_STEP_ONE_XCD"); return !(v && v[0] == '0'); }();
     const int nb = (int)(n->h1 / kStepHS);
     const int cw = padded_classes(n->out);
     const size_t lds = step_lds_bytes((int)n->h2, cw);

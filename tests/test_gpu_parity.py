@@ -313,11 +313,17 @@ def test_pretrain_cli_schedule_small_file(sz, po):
         np.testing.assert_allclose(p, q, atol=1e-4)
 
 
-@pytest.mark.parametrize("dims,batch", [((60, 64, 128, 5), 3), ((60, 512, 256, 16), 8), ((60, 96, 48, 1), 1), ((60, 64, 32, 20), 8)])
-def test_pretrain_resident_step_kernel_edge_cases(sz, po, dims, batch):
-    # batches of <= 8 rows run as one resident kernel (several workgroups, one grid barrier per
+@pytest.mark.parametrize("one_xcd", ["1", "0"])
+@pytest.mark.parametrize("dims,batch", [((60, 64, 128, 5), 3), ((60, 512, 256, 16), 8), ((60, 96, 48, 1), 1), ((60, 64, 32, 20), 8),
+                                        ((60, 1024, 256, 16), 8), ((60, 1056, 64, 3), 5)])
+def test_pretrain_resident_step_kernel_edge_cases(sz, po, dims, batch, one_xcd, monkeypatch):
+    # batches of <= 8 rows run as one resident kernel (several workgroups, one exchange per
     # step); here with a ragged last batch, one batch whose rows are all dropped to zero (no
-    # update, lib.rs:1003-1005), single dead rows, and three epochs
+    # update, lib.rs:1003-1005), single dead rows, and three epochs.  Both exchanges: the
+    # workgroups on one XCD adding fixed-point partials in its L2 (up to 32 workgroups = 1024
+    # hidden-1 units), and spread over the chip with flags and slots (STREAMZ_STEP_ONE_XCD=0,
+    # or more than 32 workgroups)
+    monkeypatch.setenv("STREAMZ_STEP_ONE_XCD", one_xcd)
     rng = np.random.default_rng(11)
     n, epochs = 4 * batch + max(1, batch // 2), 3
     onet = po.Net(*dims)
