@@ -116,10 +116,9 @@ SZ_HD void read_row(const float* R, int row, v2f (&x)[20])
 // |X[k]|^2 and |X[400-k]|^2 with X the 800-point DFT of the real window.
 SZ_HD void split_pair(v2f P, v2f Q, v2f w, float& pk, float& pn)
 {
-    const v2f cq = conj(Q);
-    const v2f A = P + cq;
-    const v2f B = mul_negi(cmul(w, P - cq));
-    const v2f X = A + B, Xn = A - B;
+    const v2f A = add_conj(P, Q);
+    const v2f C = cmul(w, sub_conj(P, Q));
+    const v2f X = add_negi(A, C), Xn = sub_negi(A, C);
     pk = X[0] * X[0] + X[1] * X[1];
     pn = Xn[0] * Xn[0] + Xn[1] * Xn[1];
 }
