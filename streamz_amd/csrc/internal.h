@@ -77,6 +77,9 @@ int augment_dev(const int16_t* in, uint64_t n, float gain, float noise_level, ui
 // ---- network -------------------------------------------------------------------------
 struct Workspace {
     uint64_t rows = 0;  // capacity in rows
+    // first row the forward / vote path works in: callers that keep several batches in flight on
+    // different streams (the tiled identify) give each its own range of rows
+    uint64_t row_base = 0;
     int ldx = 0;        // row stride of xd
     uint32_t out = 0;   // output width it was sized for
     float *xd = nullptr, *h1 = nullptr, *h2 = nullptr, *p = nullptr, *d2 = nullptr, *d1 = nullptr, *slab = nullptr,
@@ -179,6 +182,8 @@ int net_vote_dev(Net* n, const float* x_dev, uint64_t rows, float threshold, uns
 int net_pool_host(Net* n, const float* x_dev, uint64_t rows, int mode, float* out);
 // sizes the workspace for calls of up to `rows` rows, so that later calls allocate nothing
 int net_reserve_rows(Net* n, uint64_t rows);
+// rows the workspace holds after net_reserve_rows (a request may be capped)
+uint64_t net_workspace_rows(const Net* n);
 // device buffer `slot` of at least `bytes` (grow-only, owned by the net; call with n->mu held)
 int net_stage_dev(Net* n, int slot, size_t bytes, void** out);
 // pinned host buffer of at least `bytes` (grow-only; small transfers go through it without a pageable-copy stall)

@@ -1461,9 +1461,11 @@ int forward_hidden(Net* n, const float* x, uint64_t rows, bool relu2, hipStream_
 {
     Workspace& w = n->ws;
     const float* P = n->d_params;
+    float* const h1 = w.h1 + w.row_base * n->h1;
+    float* const h2 = w.h2 + w.row_base * n->h2;
     GemmArgs g{};
     g.A = x; g.lda = ldx ? ldx : (int)n->in; g.a_pad = ldx ? 1 : 0;
-    g.B = P + n->off_w1(); g.ldb = n->h1; g.C = w.h1; g.ldc = n->h1;
+    g.B = P + n->off_w1(); g.ldb = n->h1; g.C = h1; g.ldc = n->h1;
     g.M = (int)rows; g.N = n->h1; g.K = n->in; g.k_chunk = n->in; g.bias = P + n->off_b1();
     g.mask = relu_mask;
     int rc;
@@ -1476,7 +1478,7 @@ int forward_hidden(Net* n, const float* x, uint64_t rows, bool relu2, hipStream_
     }
     if (rc) return rc;
     g = GemmArgs{};
-    g.A = w.h1; g.lda = n->h1; g.B = P + n->off_w2(); g.ldb = n->h2; g.C = w.h2; g.ldc = n->h2;
+    g.A = h1; g.lda = n->h1; g.B = P + n->off_w2(); g.ldb = n->h2; g.C = h2; g.ldc = n->h2;
     g.M = (int)rows; g.N = n->h2; g.K = n->h1; g.k_chunk = n->h1; g.bias = P + n->off_b2();
     if (x3) {  // B as [hidden2][hidden1] planes
         g.B = (const float*)w.w2s; g.ldb = n->h1; g.b_plane = (uint64_t)n->h1 * n->h2;
@@ -1496,7 +1498,7 @@ int forward_logits(Net* n, uint64_t rows, float* out, hipStream_t s, bool x3 = f
     Workspace& w = n->ws;
     const float* P = n->d_params;
     GemmArgs g{};
-    g.A = w.h2; g.lda = n->h2; g.B = P + n->off_w3(); g.ldb = n->out; g.C = out; g.ldc = n->out;
+    g.A = w.h2 + w.row_base * n->h2; g.lda = n->h2; g.B = P + n->off_w3(); g.ldb = n->out; g.C = out; g.ldc = n->out;
     g.M = (int)rows; g.N = n->out; g.K = n->h2; g.k_chunk = n->h2; g.bias = P + n->off_b3();
     if (x3) {  // B as [classes][hidden2] planes
         g.B = (const float*)w.w3s; g.ldb = n->h2; g.b_plane = (uint64_t)n->h2 * n->out;
@@ -2118,6 +2120,7 @@ int net_pool_host(Net* n, const float* x_dev, uint64_t rows, int mode, float* ou
 }
 
 int net_reserve_rows(Net* n, uint64_t rows) { return ensure_workspace(n, rows); }
+uint64_t net_workspace_rows(const Net* n) { return n->ws.rows; }
 
 int net_stage_dev(Net* n, int slot, size_t bytes, void** out)
 {
@@ -2149,8 +2152,12 @@ int net_vote_dev(Net* n, const float* x_dev, uint64_t rows, float threshold, uns
                  double* psums_dev, hipStream_t s)
 {
     if (rows == 0 || n->out == 0) return SZH_OK;
-    int rc = ensure_workspace(n, rows);
+    const uint64_t base = n->ws.row_base;
+    if (base != 0 && (rows > chunk_rows(n) || base + rows > n->ws.rows)) { set_error("vote: rows beyond the reserved workspace"); return SZH_EINVAL; }
+    int rc = ensure_workspace(n, base + rows);
     if (rc) return rc;
+    const float* h2 = n->ws.h2 + base * n->h2;
+    float* p = n->ws.p + base * n->out;
     for (uint64_t r0 = 0; r0 < rows; r0 += chunk_rows(n)) {
         const uint64_t R = std::min<uint64_t>(chunk_rows(n), rows - r0);
         rc = forward_hidden(n, x_dev + r0 * n->in, R, false, s);
@@ -2160,25 +2167,25 @@ int net_vote_dev(Net* n, const float* x_dev, uint64_t rows, float threshold, uns
             const float* P = n->d_params;
             const float *w3 = P + n->off_w3(), *b3 = P + n->off_b3();
             switch (ncb) {
-            case 1: rc = launch_vote_head<1>(n->ws.h2, R, (int)n->h2, w3, b3, (int)n->out, threshold, counts_dev, psums_dev, s); break;
-            case 2: rc = launch_vote_head<2>(n->ws.h2, R, (int)n->h2, w3, b3, (int)n->out, threshold, counts_dev, psums_dev, s); break;
-            case 3: rc = launch_vote_head<3>(n->ws.h2, R, (int)n->h2, w3, b3, (int)n->out, threshold, counts_dev, psums_dev, s); break;
-            default: rc = launch_vote_head<4>(n->ws.h2, R, (int)n->h2, w3, b3, (int)n->out, threshold, counts_dev, psums_dev, s); break;
+            case 1: rc = launch_vote_head<1>(h2, R, (int)n->h2, w3, b3, (int)n->out, threshold, counts_dev, psums_dev, s); break;
+            case 2: rc = launch_vote_head<2>(h2, R, (int)n->h2, w3, b3, (int)n->out, threshold, counts_dev, psums_dev, s); break;
+            case 3: rc = launch_vote_head<3>(h2, R, (int)n->h2, w3, b3, (int)n->out, threshold, counts_dev, psums_dev, s); break;
+            default: rc = launch_vote_head<4>(h2, R, (int)n->h2, w3, b3, (int)n->out, threshold, counts_dev, psums_dev, s); break;
             }
             if (rc) return rc;
             continue;
         }
-        rc = forward_logits(n, R, n->ws.p, s);
+        rc = forward_logits(n, R, p, s);
         if (rc) return rc;
-        rc = launch_softmax(n->ws.p, R, (int)n->out, 0, nullptr, nullptr, nullptr, nullptr, s);
+        rc = launch_softmax(p, R, (int)n->out, 0, nullptr, nullptr, nullptr, nullptr, s);
         if (rc) return rc;
         if (counts_dev) {
             hipLaunchKernelGGL(vote_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), n->out * sizeof(unsigned int), s,
-                               n->ws.p, R, (int)n->out, threshold, counts_dev);
+                               p, R, (int)n->out, threshold, counts_dev);
             SZ_HIP(hipGetLastError());
         }
         if (psums_dev) {
-            hipLaunchKernelGGL(prob_sum_kernel, dim3((unsigned)std::min<uint64_t>((R + 63) / 64, 1024)), dim3(256), 0, s, n->ws.p, R,
+            hipLaunchKernelGGL(prob_sum_kernel, dim3((unsigned)std::min<uint64_t>((R + 63) / 64, 1024)), dim3(256), 0, s, p, R,
                                (int)n->out, psums_dev);
             SZ_HIP(hipGetLastError());
         }

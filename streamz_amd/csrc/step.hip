@@ -187,7 +187,6 @@ __global__ __launch_bounds__(kStepThreads) void step_kernel(StepArgs a)
     float* __restrict__ tgt = sm + L.tgt;  // [CW]
     float* __restrict__ xsb = sm + L.xs;   // 2 x [16][60] (+ pad): this step's rows / the next step's; rows 8..15 stay zero
     float* __restrict__ h1s = sm + L.h1;   // [16][LDH1] row-major, rows 8..15 stay zero
-    float* __restrict__ d1s = sm + L.d1;   // [8][HS]
     float* __restrict__ h2s = sm + L.h2;   // [16][LD2], rows 8..15 stay zero
     float* __restrict__ d2s = sm + L.d2;   // [16][LD2], rows 8..15 stay zero
     float* __restrict__ d3w = sm + L.d3 + wave * 16 * LDD3;  // this wave's copy of delta3 [16][LDD3], rows 8..15 zero

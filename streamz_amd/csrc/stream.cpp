@@ -9,6 +9,7 @@
 // instead of keeping state between tiles.  Edge replication (lib.rs:215-220) happens only in
 // the first and the last tile, which are launched directly.
 #include <algorithm>
+#include <cstdlib>
 #include <vector>
 
 #include "internal.h"
@@ -19,8 +20,18 @@ namespace sz {
 
 namespace {
 
+constexpr int kMaxLanes = 4;   // tiles of device-resident PCM kept in flight at once
+
 struct Resources {
     hipStream_t compute = nullptr, copy = nullptr;
+    // device-resident PCM: interior tiles go round-robin to `lanes` streams, each with its own plan,
+    // feature rows, range of workspace rows and captured graph, so that a tile too small to fill the
+    // chip overlaps with its neighbours
+    hipStream_t lane_stream[kMaxLanes] = {};
+    Plan* lane_plan[kMaxLanes] = {};
+    hipGraph_t lane_graph[kMaxLanes] = {};
+    hipGraphExec_t lane_exec[kMaxLanes] = {};
+    Net* net = nullptr;
     hipEvent_t ready[2] = {nullptr, nullptr}, done[2] = {nullptr, nullptr};
     hipGraph_t graph[2] = {nullptr, nullptr};
     hipGraphExec_t exec[2] = {nullptr, nullptr};
@@ -31,6 +42,14 @@ struct Resources {
     {
         if (compute) (void)hipStreamSynchronize(compute);
         if (copy) (void)hipStreamSynchronize(copy);
+        for (int i = 0; i < kMaxLanes; ++i) {
+            if (lane_stream[i]) (void)hipStreamSynchronize(lane_stream[i]);
+            if (lane_exec[i]) (void)hipGraphExecDestroy(lane_exec[i]);
+            if (lane_graph[i]) (void)hipGraphDestroy(lane_graph[i]);
+            plan_destroy(lane_plan[i]);
+            if (lane_stream[i]) (void)hipStreamDestroy(lane_stream[i]);
+        }
+        if (net) net->ws.row_base = 0;
         for (int i = 0; i < 2; ++i) {
             if (exec[i]) (void)hipGraphExecDestroy(exec[i]);
             if (graph[i]) (void)hipGraphDestroy(graph[i]);
@@ -96,9 +115,21 @@ int identify_tiled(Net* n, Extractor* e, const int16_t* pcm, bool pcm_on_device,
     const uint64_t n_mid = single ? 0 : (nw - B - 3) / B;
     const uint64_t last_first = B + n_mid * B;            // first window of the last tile
     const uint64_t last_rows = single ? 0 : nw - last_first;
-    const uint64_t feat_rows = single ? nw : std::max<uint64_t>(B, last_rows);
+    // rows of features and of network workspace: one range of B rows per tile in flight
+    uint64_t max_lanes = 1;
+    if (pcm_on_device && !single && n_mid >= 2 && !prof_enabled()) {
+        static const int env_lanes = [] { const char* v = std::getenv("STREAMZ_TILE_LANES"); return v ? std::atoi(v) : 0; }();
+        // three by default: with four, the lanes' streams compete for the process's four hardware queues
+        // (100 h in tiles of 8192 windows: 0.38 s with one lane, 0.24 with two, 0.21 with three, 0.25 with four)
+        max_lanes = env_lanes > 0 ? (uint64_t)std::min(env_lanes, kMaxLanes) : (B <= 65536 ? 3 : 1);
+    }
+    uint64_t feat_rows = single ? nw : std::max<uint64_t>(B * max_lanes, last_rows);
     int rc = net_reserve_rows(n, feat_rows);
     if (rc) return rc;
+    if (max_lanes > 1 && net_workspace_rows(n) < B * max_lanes) {   // the reservation was capped
+        max_lanes = std::max<uint64_t>(1, net_workspace_rows(n) / B);
+        feat_rows = std::max<uint64_t>(B * max_lanes, last_rows);
+    }
     SZ_HIP(hipMalloc(&r.feat, feat_rows * kFeat * sizeof(float)));
     float* feat = static_cast<float*>(r.feat);
 
@@ -115,28 +146,46 @@ int identify_tiled(Net* n, Extractor* e, const int16_t* pcm, bool pcm_on_device,
         if (rc) return rc;
         rc = run_tile(n, r.first, pcm, feat, B, tally, r.compute);
         if (rc) return rc;
-        if (n_mid) {
+        if (n_mid && prof_enabled()) {
+            // event pairs inside a captured sequence would be replayed, not re-recorded
             rc = plan_create_tile(e, (B - 2) * kHop, 2, (uint32_t)B, 2, &r.mid);
             if (rc) return rc;
-            if (prof_enabled()) {
-                // event pairs inside a captured sequence would be replayed, not re-recorded
-                for (uint64_t t = 0; t < n_mid && rc == SZH_OK; ++t) {
-                    rc = run_tile(n, r.mid, pcm, feat, B, tally, r.compute);
-                    if (rc == SZH_OK) rc = plan_advance(r.mid, B * kHop, r.compute);
-                }
-                if (rc) return rc;
-            } else {
-                rc = capture_tile(r, 0, n, pcm, (uint32_t)B, tally, B * kHop);
-                if (rc) return rc;
-                for (uint64_t t = 0; t < n_mid; ++t) {
-                    SZ_HIP(hipGraphLaunch(r.exec[0], r.compute));
-                    // Bound the replays in flight.  Thousands of queued replays (4 843 for 100 h) exhaust
-                    // driver-side state that other processes need: while they were queued, and for as
-                    // long as this process lived afterwards, any newly started process on the GPU
-                    // crashed in its first kernel launch.
-                    if ((t & 255) == 255) SZ_HIP(hipStreamSynchronize(r.compute));
-                }
+            for (uint64_t t = 0; t < n_mid && rc == SZH_OK; ++t) {
+                rc = run_tile(n, r.mid, pcm, feat, B, tally, r.compute);
+                if (rc == SZH_OK) rc = plan_advance(r.mid, B * kHop, r.compute);
             }
+            if (rc) return rc;
+        } else if (n_mid) {
+            // Lane l takes interior tiles l, l + lanes, ...: its plan starts at tile l and moves on by
+            // `lanes` tiles per replay; its features and its workspace rows are the l-th range of B rows.
+            const int lanes = (int)std::min<uint64_t>(std::min<uint64_t>(n_mid, (uint64_t)max_lanes), kMaxLanes);
+            r.net = n;
+            for (int l = 0; l < lanes; ++l) {
+                SZ_HIP(hipStreamCreateWithFlags(&r.lane_stream[l], hipStreamNonBlocking));
+                rc = plan_create_tile(e, (B - 2 + (uint64_t)l * B) * kHop, 2, (uint32_t)B, 2, &r.lane_plan[l]);
+                if (rc) return rc;
+                n->ws.row_base = (uint64_t)l * B;
+                SZ_HIP(hipStreamBeginCapture(r.lane_stream[l], hipStreamCaptureModeRelaxed));
+                rc = run_tile(n, r.lane_plan[l], pcm, feat + (uint64_t)l * B * kFeat, B, tally, r.lane_stream[l]);
+                if (rc == SZH_OK) rc = plan_advance(r.lane_plan[l], (uint64_t)lanes * B * kHop, r.lane_stream[l]);
+                const hipError_t he = hipStreamEndCapture(r.lane_stream[l], &r.lane_graph[l]);
+                n->ws.row_base = 0;
+                if (rc) return rc;
+                if (he != hipSuccess) return hip_fail(he, "hipStreamEndCapture");
+                SZ_HIP(hipGraphInstantiate(&r.lane_exec[l], r.lane_graph[l], nullptr, nullptr, 0));
+            }
+            // the first tile (direct launches on r.compute) used the rows of lane 0
+            SZ_HIP(hipStreamSynchronize(r.compute));
+            for (uint64_t t = 0; t < n_mid; ++t) {
+                SZ_HIP(hipGraphLaunch(r.lane_exec[t % lanes], r.lane_stream[t % lanes]));
+                // Bound the replays in flight.  Thousands of queued replays (4 843 for 100 h) exhaust
+                // driver-side state that other processes need: while they were queued, and for as
+                // long as this process lived afterwards, any newly started process on the GPU
+                // crashed in its first kernel launch.
+                if ((t & 255) == 255)
+                    for (int l = 0; l < lanes; ++l) SZ_HIP(hipStreamSynchronize(r.lane_stream[l]));
+            }
+            for (int l = 0; l < lanes; ++l) SZ_HIP(hipStreamSynchronize(r.lane_stream[l]));
         }
         rc = plan_create_tile(e, (last_first - 2) * kHop, 2, (uint32_t)last_rows, 0, &r.last);
         if (rc) return rc;
