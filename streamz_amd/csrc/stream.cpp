@@ -118,7 +118,8 @@ int identify_tiled(Net* n, Extractor* e, const int16_t* pcm, bool pcm_on_device,
     // rows of features and of network workspace: one range of B rows per tile in flight
     uint64_t max_lanes = 1;
     if (pcm_on_device && !single && n_mid >= 2 && !prof_enabled()) {
-        static const int env_lanes = [] { const char* v = std::getenv("STREAMZ_TILE_LANES"); return v ? std::atoi(v) : 0; }();
+        const char* env_v = std::getenv("STREAMZ_TILE_LANES");
+        const int env_lanes = env_v ? std::atoi(env_v) : 0;
         // three by default: with four, the lanes' streams compete for the process's four hardware queues
         // (100 h in tiles of 8192 windows: 0.38 s with one lane, 0.24 with two, 0.21 with three, 0.25 with four)
         max_lanes = env_lanes > 0 ? (uint64_t)std::min(env_lanes, kMaxLanes) : (B <= 65536 ? 3 : 1);

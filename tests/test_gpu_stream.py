@@ -97,6 +97,24 @@ def test_ragged_lengths_equal_one_piece(sz, nets):
     assert ids == [] and counts.sum() == 0
 
 
+@pytest.mark.parametrize("lanes", ["1", "2", "3", "4"])
+def test_votes_do_not_depend_on_the_tiles_in_flight(sz, nets, lanes, monkeypatch):
+    """Interior tiles of device-resident PCM run on several streams at once (each with its own plan, feature
+    rows, workspace rows and graph); the votes equal the one-piece path's for every number of lanes,
+    including window counts that leave a lane without a tile in the last round."""
+    net, _ = nets
+    ext = sz.FeatureExtractor()
+    rng = np.random.default_rng(16)
+    monkeypatch.setenv("STREAMZ_TILE_LANES", lanes)
+    B = 32
+    full = noise_pcm(rng, 400 * 14 * B + 800)
+    for nw in (4 * B + 3, 7 * B + 5, 13 * B + 2):
+        pcm = full[: 400 * (nw - 1) + 800]
+        _, one = dev_counts(sz, net, ext, pcm, 0.1, 1 << 20)
+        _, tiled = dev_counts(sz, net, ext, pcm, 0.1, B)
+        np.testing.assert_array_equal(tiled, one, err_msg=f"{nw} windows, {lanes} lanes")
+
+
 def test_profiled_run_gives_the_same_votes(sz, nets):
     net, _ = nets
     ext = sz.FeatureExtractor()
