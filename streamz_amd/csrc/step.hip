@@ -278,6 +278,60 @@ __global__ __launch_bounds__(kStepThreads) void step_kernel(StepArgs a)
     __amdgpu_buffer_rsrc_t acc_rs = __builtin_amdgcn_make_buffer_rsrc(a.acc, 0, ONEX ? 3 * H2 * kStepRows * 8 : 0, 0x00020000);
     int acc_cur = 0;
 
+    // The output layer's share of a step's update: w3 (this wave's rows of it, i.e. its own columns of the
+    // second layer), b2 of those columns and b3.  Nothing before the sums of the next step's exchange are
+    // in needs them, so they are applied while that exchange is under way (and once after the last step),
+    // from h2, delta2 and delta3 of the step they belong to, which stay in LDS until then.
+    //   dW3 = h2^T . delta3 (rows of w3 x classes, K = the 8 rows): register v of lane (class m16, g4) is
+    //   row 16 t + 4 g4 + v, 16 contiguous bytes of W3T.
+    bool out_pending = false;
+    float out_scale = 0.0f;
+    auto output_updates = [&](const int (&tt)[TPWMAX]) {
+        float d3f[kStepMaxC / 16][kStepRows / 4], hf[TPWMAX][kStepRows / 4];
+        f32x4 w3o[kStepMaxC / 16][TPWMAX];
+#pragma unroll
+        for (int st = 0; st < kStepRows / 4; ++st) {
+#pragma unroll
+            for (int h = 0; h < kStepMaxC / 16; ++h) d3f[h][st] = 16 * h < CW ? d3w[(4 * st + g4) * LDD3 + 16 * h + m16] : 0.0f;
+#pragma unroll
+            for (int u = 0; u < TPWMAX; ++u) hf[u][st] = h2s[(4 * st + g4) * LD2 + 16 * tt[u] + m16];
+        }
+#pragma unroll
+        for (int u = 0; u < TPWMAX; ++u)
+#pragma unroll
+            for (int h = 0; h < kStepMaxC / 16; ++h)
+                w3o[h][u] = 16 * h < CW ? *reinterpret_cast<const f32x4*>(W3T + (16 * h + m16) * LD3 + 16 * tt[u] + 4 * g4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        float g2 = 0.0f, g3 = 0.0f;
+        if (lane < 16 * ntw) {
+#pragma unroll
+            for (int r = 0; r < kStepRows; ++r) g2 += d2s[r * LD2 + 16 * t0 + lane];
+        }
+        if (wave == 0 && lane < C) {
+#pragma unroll
+            for (int r = 0; r < kStepRows; ++r) g3 += d3w[r * LDD3 + lane];
+        }
+        SZ_SCHED_FENCE();
+        f32x4 acc3[kStepMaxC / 16][TPWMAX];
+#pragma unroll
+        for (int h = 0; h < kStepMaxC / 16; ++h)
+            if (16 * h < CW) {
+#pragma unroll
+                for (int u = 0; u < TPWMAX; ++u) acc3[h][u] = SZ_MFMA16(hf[u][0], d3f[h][0], (f32x4{0.f, 0.f, 0.f, 0.f}));
+#pragma unroll
+                for (int u = 0; u < TPWMAX; ++u) acc3[h][u] = SZ_MFMA16(hf[u][1], d3f[h][1], acc3[h][u]);
+            }
+        SZ_SCHED_FENCE();
+#pragma unroll
+        for (int h = 0; h < kStepMaxC / 16; ++h)
+#pragma unroll
+            for (int u = 0; u < TPWMAX; ++u)
+                if (16 * h < CW && 16 * h + m16 < C && u < ntw)
+                    *reinterpret_cast<f32x4*>(W3T + (16 * h + m16) * LD3 + 16 * tt[u] + 4 * g4) = w3o[h][u] - out_scale * acc3[h][u];
+        if (lane < 16 * ntw) b2s[16 * t0 + lane] -= out_scale * g2;   // b2 of the own columns
+        if (wave == 0 && lane < C) b3s[lane] -= out_scale * g3;
+        out_pending = false;
+    };
+
     bool healthy = true;
     if (a.force_abort && blk == NB - 1) {
         if (tid == 0) __hip_atomic_store(a.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -371,6 +425,7 @@ __global__ __launch_bounds__(kStepThreads) void step_kernel(StepArgs a)
                                                                (buf * NB + blk) * slot_bytes + ((16 * tt[u] + m16) * kStepRows + 4 * g4) * 4u, 0, kAux);
             }
         }
+        if (out_pending) output_updates(tt);   // the previous step's w3, b3, b2 updates, behind this step's stores
         STEP_MARK(2);   // partial h2 computed and stored
         if (!ONEX) {
             // 3. publish: every storing wave drains its write-through stores, then one lane raises the flag
@@ -641,34 +696,23 @@ __global__ __launch_bounds__(kStepThreads) void step_kernel(StepArgs a)
             // Reads of everything the rest of 7. needs, then its matrix instructions back to back:
             //   delta1 of the own units, delta2 . w2[own, :]^T with the old w2: this wave's share of K
             //     (its own columns), two tiles of 16 units;
-            //   dW3 = h2^T . delta3 for the own rows of w3 (rows of w3 x classes, K = the 8 rows):
-            //     register v of lane (class m16, g4) is row 16 t + 4 g4 + v, 16 contiguous bytes of W3T;
             //   dW2^T = delta2^T . h1 for the own columns (columns x units, K = the 8 rows): register v
             //     of lane (unit m16, g4) is column 16 t + 4 g4 + v, 16 contiguous bytes of a W2s row.
             static_assert(kStepHS == 32, "two tiles of 16 units");
             f32x4 dv[TPWMAX];
-            float d3f[kStepMaxC / 16][kStepRows / 4], hf[TPWMAX][kStepRows / 4], h1f[2][kStepRows / 4], d2f[TPWMAX][kStepRows / 4];
-            f32x4 w3o[kStepMaxC / 16][TPWMAX];
+            float h1f[2][kStepRows / 4], d2f[TPWMAX][kStepRows / 4];
             f32x4 w2o[TPWMAX][2];
 #pragma unroll
             for (int u = 0; u < TPWMAX; ++u) dv[u] = *reinterpret_cast<const f32x4*>(d2s + m16 * LD2 + 16 * tt[u] + 4 * g4);
 #pragma unroll
             for (int st = 0; st < kStepRows / 4; ++st) {
 #pragma unroll
-                for (int h = 0; h < kStepMaxC / 16; ++h) d3f[h][st] = 16 * h < CW ? d3w[(4 * st + g4) * LDD3 + 16 * h + m16] : 0.0f;
-#pragma unroll
                 for (int ib = 0; ib < 2; ++ib) h1f[ib][st] = h1s[(4 * st + g4) * LDH1 + 16 * ib + m16];
 #pragma unroll
-                for (int u = 0; u < TPWMAX; ++u) {
-                    hf[u][st] = h2s[(4 * st + g4) * LD2 + 16 * tt[u] + m16];
-                    d2f[u][st] = d2s[(4 * st + g4) * LD2 + 16 * tt[u] + m16];
-                }
+                for (int u = 0; u < TPWMAX; ++u) d2f[u][st] = d2s[(4 * st + g4) * LD2 + 16 * tt[u] + m16];
             }
 #pragma unroll
             for (int u = 0; u < TPWMAX; ++u) {
-#pragma unroll
-                for (int h = 0; h < kStepMaxC / 16; ++h)
-                    w3o[h][u] = 16 * h < CW ? *reinterpret_cast<const f32x4*>(W3T + (16 * h + m16) * LD3 + 16 * tt[u] + 4 * g4) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int ib = 0; ib < 2; ++ib) w2o[u][ib] = *reinterpret_cast<const f32x4*>(W2s + (16 * ib + m16) * LD2 + 16 * tt[u] + 4 * g4);
             }
@@ -683,15 +727,7 @@ __global__ __launch_bounds__(kStepThreads) void step_kernel(StepArgs a)
                         acc1 = SZ_MFMA16(dv[u][q], w2b[u][q], acc1);
                     }
                 }
-            f32x4 acc3[kStepMaxC / 16][TPWMAX], acc2[TPWMAX][2];
-#pragma unroll
-            for (int h = 0; h < kStepMaxC / 16; ++h)
-                if (16 * h < CW) {
-#pragma unroll
-                    for (int u = 0; u < TPWMAX; ++u) acc3[h][u] = SZ_MFMA16(hf[u][0], d3f[h][0], (f32x4{0.f, 0.f, 0.f, 0.f}));
-#pragma unroll
-                    for (int u = 0; u < TPWMAX; ++u) acc3[h][u] = SZ_MFMA16(hf[u][1], d3f[h][1], acc3[h][u]);
-                }
+            f32x4 acc2[TPWMAX][2];
 #pragma unroll
             for (int u = 0; u < TPWMAX; ++u)
 #pragma unroll
@@ -709,31 +745,15 @@ __global__ __launch_bounds__(kStepThreads) void step_kernel(StepArgs a)
                 }
             }
 #pragma unroll
-            for (int h = 0; h < kStepMaxC / 16; ++h)
-#pragma unroll
-                for (int u = 0; u < TPWMAX; ++u)
-                    if (16 * h < CW && 16 * h + m16 < C && u < ntw)
-                        *reinterpret_cast<f32x4*>(W3T + (16 * h + m16) * LD3 + 16 * tt[u] + 4 * g4) = w3o[h][u] - scale * acc3[h][u];
-#pragma unroll
             for (int u = 0; u < TPWMAX; ++u)
                 if (u < ntw) {
 #pragma unroll
                     for (int ib = 0; ib < 2; ++ib)
                         *reinterpret_cast<f32x4*>(W2s + (16 * ib + m16) * LD2 + 16 * tt[u] + 4 * g4) = w2o[u][ib] - scale * acc2[u][ib];
                 }
-            if (lane < 16 * ntw) {   // b2 of the own columns
-                const int k = 16 * t0 + lane;
-                float g2 = 0.0f;
-#pragma unroll
-                for (int r = 0; r < kStepRows; ++r) g2 += d2s[r * LD2 + k];
-                b2s[k] -= scale * g2;
-            }
-            if (wave == 0 && lane < C) {
-                float g = 0.0f;
-#pragma unroll
-                for (int r = 0; r < kStepRows; ++r) g += d3w[r * LDD3 + lane];
-                b3s[lane] -= scale * g;
-            }
+            // the updates of w3, b3 and b2 wait until the next step's exchange is under way (output_updates)
+            out_pending = true;
+            out_scale = scale;
             __syncthreads();
             STEP_MARK(11);  // w2 update
             // 8. delta1[row 4 st + g4][unit 16 ib + m16], the operand of dW1: every lane sums the four
@@ -801,6 +821,13 @@ __global__ __launch_bounds__(kStepThreads) void step_kernel(StepArgs a)
         for (int i = 0; i < kStepProfSlots; ++i) a.prof[i] = pacc[i];
 #undef STEP_MARK
     if (!healthy) return;  // the host discards the shadow vector
+    if (out_pending) {   // the last step's w3, b3, b2 updates
+        int tt[TPWMAX];
+#pragma unroll
+        for (int u = 0; u < TPWMAX; ++u) tt[u] = min(t0 + min(u, TPW - 1), NT - 1);
+        output_updates(tt);
+    }
+    __syncthreads();
     // the owned parameters go to the shadow vector; workgroup 0 also writes the replicated ones and the totals
     float* Pw = a.params_out;
     for (int e = tid; e < IN * HS; e += kStepThreads) { const int j = e / HS, i = e - j * HS; Pw[(size_t)j * a.h1 + i0 + i] = W1s[j * LDW1 + i]; }
