@@ -33,6 +33,7 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <type_traits>
@@ -916,7 +917,9 @@ int net_pretrain_steps(Net* n, const float* d_win, uint32_t n_win, const uint32_
     // First with all workgroups on one XCD (they must fit its CUs, one each), then spread over the chip.
     // A launch that did not run every step leaves the parameters alone, so the next one starts afresh.
     bool ran = false;
-    for (int onex = (one_xcd_on && nb <= cus / 8) ? 1 : 0; onex >= 0 && !ran; --onex) {
+    // a process whose one-XCD launch once failed to assemble does not try (and wait for) it again
+    static std::atomic<bool> one_xcd_failed{false};
+    for (int onex = (one_xcd_on && !one_xcd_failed.load() && nb <= cus / 8) ? 1 : 0; onex >= 0 && !ran; --onex) {
         StepFn fn = prof_on ? (onex ? pick_step_kernel<true, true>((int)n->h2, cw) : pick_step_kernel<true, false>((int)n->h2, cw))
                             : (onex ? pick_step_kernel<false, true>((int)n->h2, cw) : pick_step_kernel<false, false>((int)n->h2, cw));
         SZ_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -932,7 +935,8 @@ int net_pretrain_steps(Net* n, const float* d_win, uint32_t n_win, const uint32_
         SZ_HIP(hipGetLastError());
         SZ_HIP(hipMemcpyAsync(&tail, a.abort_flag, sizeof(tail), hipMemcpyDeviceToHost, s));
         SZ_HIP(hipStreamSynchronize(s));
-        ran = tail.abort == 0;
+        // a one-XCD launch also has to have handed out every role (no workgroup on XCD 0 means no abort either)
+        ran = tail.abort == 0 && (!onex || tail.pad[0] >= nb);
         if (onex && std::getenv("STREAMZ_STEP_DEBUG")) {
             unsigned f[kStepMaxBlocks + 2] = {};
             (void)hipMemcpy(f, a.flags, sizeof(f), hipMemcpyDeviceToHost);
@@ -941,6 +945,7 @@ int net_pretrain_steps(Net* n, const float* d_win, uint32_t n_win, const uint32_
             std::fprintf(stderr, "\n");
         }
         if (!ran && a.force_abort) break;   // the test hook asks for the failure itself
+        if (!ran && onex) one_xcd_failed.store(true);
     }
     if (d_prof && ran) {
         unsigned long long h[kStepProfSlots] = {};
