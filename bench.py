@@ -218,6 +218,9 @@ def main():
         # library's own RCCL all-reduce on the gradient vector (szh_net_allreduce_grad_dev).
         import torch.distributed as dist
         os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+        # RCCL's bootstrap (rendezvous of the ranks' communicators) is a socket exchange too; all ranks are on
+        # this node, so the loopback interface always reaches them (the data path is xGMI / device memory)
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
         if args.share_gpu:
             local_rank %= torch.cuda.device_count()  # rehearsal: ranks share a GPU, gradients summed on the host
         torch.cuda.set_device(local_rank)
