@@ -36,7 +36,6 @@
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>
-#include <type_traits>
 
 #include "internal.h"
 #include "prof.h"
@@ -167,7 +166,6 @@ __global__ __launch_bounds__(kStepThreads) void step_kernel(StepArgs a)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     __builtin_assume(wave >= 0 && wave < kStepThreads / 64);
     const int NB = ONEX ? a.nb : (int)gridDim.x, blk = role;
-    constexpr int kAux = ONEX ? 0 : 16;   // cache policy of the slot accesses: plain, or sc1
     constexpr int IN = kStepIn, HS = kStepHS, LDW1 = kStepLdW1, LDH1 = kStepLdH1, TPWMAX = 4;
     const int H2 = H2T ? H2T : a.h2;
     const int C = a.out;
@@ -423,7 +421,7 @@ __global__ __launch_bounds__(kStepThreads) void step_kernel(StepArgs a)
                 for (int u = 0; u < TPWMAX; ++u)
                     if (g4 < 2 && u < ntw)
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[u]), part_rs,
-                                                               (buf * NB + blk) * slot_bytes + ((16 * tt[u] + m16) * kStepRows + 4 * g4) * 4u, 0, kAux);
+                                                               (buf * NB + blk) * slot_bytes + ((16 * tt[u] + m16) * kStepRows + 4 * g4) * 4u, 0, 16);
             }
         }
         if (out_pending) output_updates(tt);   // the previous step's w3, b3, b2 updates, behind this step's stores
@@ -542,27 +540,12 @@ __global__ __launch_bounds__(kStepThreads) void step_kernel(StepArgs a)
             for (int p = 0; p < TPWMAX / 2; ++p) poff[p] = (unsigned)(32 * tt[2 * p + (lane >> 5)] + (lane & 31)) * 16u;
             for (int b0 = 0; b0 < NB; b0 += 16) {
                 u32x4 v[TPWMAX / 2][16];
-                // Every workgroup needs every slot; workgroup b asks for them in the order b, b + 1, ... so
-                // that the workgroups are not all at the same addresses at once.  The registers a slot
-                // lands in, and with them the order of the sum, are the same everywhere.
-                auto issue = [&](auto rot) {
-                    constexpr int R = decltype(rot)::value;
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        constexpr int kMask = 15;
-                        const int b = (i + R) & kMask;
+                for (int p = 0; p < TPWMAX / 2; ++p)
 #pragma unroll
-                        for (int p = 0; p < TPWMAX / 2; ++p)
-                            if (2 * p < TPW)
-                                v[p][b] = __builtin_amdgcn_raw_buffer_load_b128(part_rs, (buf * NB + min(b0 + b, NB - 1)) * slot_bytes + poff[p], 0, kAux);
-                    }
-                };
-                switch (blk & 15) {
-#define SZ_ROT(r_) case r_: issue(std::integral_constant<int, r_>{}); break;
-                    SZ_ROT(0) SZ_ROT(1) SZ_ROT(2) SZ_ROT(3) SZ_ROT(4) SZ_ROT(5) SZ_ROT(6) SZ_ROT(7)
-                    SZ_ROT(8) SZ_ROT(9) SZ_ROT(10) SZ_ROT(11) SZ_ROT(12) SZ_ROT(13) SZ_ROT(14) SZ_ROT(15)
-#undef SZ_ROT
-                }
+                    for (int b = 0; b < 16; ++b)
+                        if (2 * p < TPW)
+                            v[p][b] = __builtin_amdgcn_raw_buffer_load_b128(part_rs, (buf * NB + min(b0 + b, NB - 1)) * slot_bytes + poff[p], 0, 16);
                 if (b0 == 0) {
                     // while those loads are in flight: the next step's values and the indices of the one after
                     SZ_SCHED_FENCE();
