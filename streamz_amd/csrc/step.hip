@@ -462,29 +462,21 @@ __global__ __launch_bounds__(kStepThreads) void step_kernel(StepArgs a)
         // All loads are sc1 and issued before the first add.
         if (ONEX) {
             // The sums of this step: a lane takes elements 2 lane and 2 lane + 1 of each of its tiles (128 a
-            // tile): one row, two columns, with sc1 loads (they never hit the CU's L1).  Loads of an element
-            // that is still being added to slow those additions down, so at first only wave 0 looks, and
-            // only at its first tile; once that shows all NB arrivals the rest has as a rule arrived as
-            // well, and every wave reads its tiles, again until each element is complete.
+            // tile): one row, two columns, with sc1 loads (they never hit the CU's L1).  Each wave reads its own
+            // tiles until every element shows all NB arrivals.  Loads of an element that is still being added
+            // to slow those additions down; the previous step's output-layer updates, which every wave has just
+            // done, keep the first look 0.6 us behind the atomics, by when most of them have landed.
             auto gave_up = [&](unsigned long long since) -> bool {
                 const unsigned long long waited = wall_clock64() - since;
                 if (waited < 2000ull) return false;   // the abort word is looked at after 20 us of waiting
                 if (waited > kStepTimeoutTicks || __hip_atomic_load(a.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
                     __hip_atomic_store(a.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    ctl[16] = 0;   // looked at after the next workgroup barrier but one
+                    ctl[16] = 0;   // looked at after the next workgroup barrier
                     return true;
                 }
                 return false;
             };
             const unsigned long long tw0 = wall_clock64();
-            if (wave == 0) {
-                for (;;) {
-                    const u32x4 s1 = __builtin_amdgcn_raw_buffer_load_b128(acc_rs, (unsigned)((acc_cur * H2 * kStepRows + tt[0] * 128 + 2 * lane) * 8), 0, 16);
-                    const bool ok = (s1[1] >> 26) == (unsigned)NB && (s1[3] >> 26) == (unsigned)NB;
-                    if (__builtin_amdgcn_ballot_w64(!ok) == 0 || gave_up(tw0)) break;
-                }
-            }
-            __syncthreads();
             u32x4 q[TPWMAX];
             auto attempt = [&]() {
 #pragma unroll
