@@ -69,12 +69,11 @@ def main():
     net = sz.SimpleNeuralNet(*DIMS, init=params)
     local, summed = epoch(net, files, labels, shard(files, world, rank), reduce=dist.all_reduce)
     np.savez(os.path.join(out, f"rank{rank}.npz"), params=net.get_flat(), local=local, summed=summed)
-    del net
+    if not os.environ.get("TWO_RANK_KEEP_NET"):   # (set: the handle outlives the process group, up to interpreter exit)
+        del net
     torch.cuda.synchronize()
-    dist.barrier()
+    dist.barrier()   # no rank leaves while its peer may still be inside the all-reduce
     dist.destroy_process_group()
-    sys.stdout.flush()
-    os._exit(0)  # the results are on disk; skip the interpreter's teardown of two HIP-using libraries
 
 
 if __name__ == "__main__":
