@@ -7,9 +7,11 @@ One "step" = one pass of the hot path over the rank's clips, everything device-r
             on the device, [all-reduce of the 0.67 MB gradient vector across ranks,] one SGD update
 windows/sec = windows of all ranks / (t_extract + t_epoch), max over ranks, K timed steps.
 
-Default workload = BASELINE.json configs[1]: 1 000 clips x 60 s, 16 speakers, net 60-512-256-16,
-per GPU (weak scaling: every rank holds its own 1 000 clips, no data-path collective except the
-per-epoch gradient all-reduce).
+Default workload = BASELINE.json configs[1]: 1 000 clips x 60 s, 16 speakers, net 60-512-256-16.
+--scaling strong (the default; the metric is quoted on one fixed set of 1 000 clips at 1/2/4/8 GPUs): the
+clips are cut into contiguous ranges balanced on window count (szh_shard_ranges), one range per rank.
+--scaling weak: every rank holds its own --clips clips.  Either way there is no data-path collective
+except the per-epoch gradient all-reduce.
 
 Launch:  python bench.py --gpus 1 --steps 3 --warmup 1
          python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
@@ -190,7 +192,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--clips", type=int, default=1000, help="clips per GPU")
+    ap.add_argument("--clips", type=int, default=1000, help="clips of the whole job (--scaling strong) or per GPU (weak)")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
+                    help="strong: --clips clips in all, sharded over the ranks by window count; weak: --clips clips per rank")
     ap.add_argument("--seconds", type=float, default=60.0)
     ap.add_argument("--speakers", type=int, default=16)
     ap.add_argument("--hidden1", type=int, default=512)
@@ -203,7 +207,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal of the N > 1 path on fewer GPUs than ranks: "
-                    "ranks share a GPU and the gradient vectors are summed on the host instead of by RCCL")
+                    "ranks share a GPU and the library's communicator sums on the host (shared memory) instead of by RCCL")
     ap.add_argument("--no-extras", action="store_true", help="skip the inference and batch-8 side measurements")
     args = ap.parse_args()
 
@@ -222,7 +226,8 @@ def main():
         # this node, so the loopback interface always reaches them (the data path is xGMI / device memory)
         os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
         if args.share_gpu:
-            local_rank %= torch.cuda.device_count()  # rehearsal: ranks share a GPU, gradients summed on the host
+            local_rank %= torch.cuda.device_count()  # rehearsal: ranks share a GPU, RCCL would refuse them
+            os.environ["STREAMZ_COMM"] = "host"      # the library's communicator then sums in shared memory
         torch.cuda.set_device(local_rank)
         dist.init_process_group("gloo")
     else:
@@ -231,7 +236,7 @@ def main():
     dev = torch.device("cuda", local_rank if multi else 0)
     sz._capi._check(sz.lib().szh_init(dev.index))
     comm, torch_rccl, comm_note = None, None, None
-    if multi and not args.share_gpu:
+    if multi:
         err = None
         try:
             if os.environ.get("BENCH_FORCE_TORCH_RCCL"):
@@ -251,19 +256,27 @@ def main():
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if int(ok.item()) == 0:
             comm = None
+            if args.share_gpu:
+                raise SystemExit("bench: the library's host communicator did not come up: %s" % err)
             torch_rccl = dist.new_group(backend="nccl")
             comm_note = "library communicator unavailable (%s): torch.distributed RCCL group on the same vector" % err
             if rank == 0:
                 print("bench: " + comm_note, file=sys.stderr)
 
     # ---- synthetic, device-resident inputs
-    pcm, offsets, lengths = synth_clips(args.clips, args.seconds, args.speakers, dev, first_clip=rank * args.clips)
+    if args.scaling == "strong":  # one fixed set of clips, cut over the ranks by window count
+        per_clip = sz.window_count(int(args.seconds * SR))
+        cut = sz.shard_ranges([per_clip] * args.clips, world)
+        first_clip, my_clips = cut[rank], cut[rank + 1] - cut[rank]
+    else:
+        first_clip, my_clips = rank * args.clips, args.clips
+    pcm, offsets, lengths = synth_clips(my_clips, args.seconds, args.speakers, dev, first_clip=first_clip)
     ext = sz.FeatureExtractor()
     plan = sz.Plan(ext, offsets, lengths)
     n_win = plan.total_windows
     feats = torch.empty((n_win, 60), dtype=torch.float32, device=dev)
     per_file = np.diff(plan.window_offsets).astype(np.int64)
-    clip_speaker = (np.arange(args.clips) + rank * args.clips) % args.speakers
+    clip_speaker = (np.arange(my_clips) + first_clip) % args.speakers
     labels = torch.from_numpy(np.repeat(clip_speaker, per_file).astype(np.int32)).to(dev)
     net = sz.SimpleNeuralNet(60, args.hidden1, args.hidden2, args.speakers, seed=42)  # same init on every rank
     net.set_gemm(args.gemm)
@@ -277,7 +290,8 @@ def main():
     def step(k, record=False):
         if record:
             ev[0].record()
-        plan.run(pcm.data_ptr(), feats.data_ptr(), stream)
+        if n_win:
+            plan.run(pcm.data_ptr(), feats.data_ptr(), stream)
         if record:
             ev[1].record()
         net.zero_grad_dev(stream)
@@ -286,10 +300,6 @@ def main():
             comm.allreduce_grad(net, stream)  # gradients, loss and live-row count summed over ranks, in place
         elif torch_rccl is not None:
             dist.all_reduce(grad, group=torch_rccl)
-        elif dist is not None:  # --share-gpu rehearsal
-            host = grad.cpu()
-            dist.all_reduce(host)
-            grad.copy_(host)
         net.apply_grad_dev(args.lr, stream)
         if record:
             ev[2].record()
@@ -320,17 +330,22 @@ def main():
 
     elapsed, prof, t_ext_ms, t_train_ms, mean_loss = timed(0, args.warmup, args.steps)
 
+    windows_by_rank = [n_win]
     if dist is not None:
         tmax = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+        gathered = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(gathered, torch.tensor([n_win], dtype=torch.int64))
+        windows_by_rank = [int(t.item()) for t in gathered]
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
         return
 
     ms_per_step = 1000.0 * elapsed / args.steps
-    value = world * n_win * args.steps / elapsed
+    total_windows = sum(windows_by_rank)
+    value = total_windows * args.steps / elapsed
 
     # ---- roofline of the dominant kernel, from the event pairs recorded during the timed steps
     C, H1, H2 = args.speakers, args.hidden1, args.hidden2
@@ -375,21 +390,28 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": ms_per_step,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": args.scaling,
         "vs_baseline": None,
         "dtype": "f32" if args.gemm == "f32" else "f32 values as three bf16 pieces each on the bf16 matrix cores, f32 accumulate",
         "data": "synthetic",
         "config": {
-            "workload": (f"configs[1]: {args.clips} x {args.seconds:g} s synthetic 44.1 kHz mono clips per GPU, "
-                         f"{args.speakers} speakers, net 60-{H1}-{H2}-{C}"),
+            "workload": (f"configs[1]: {args.clips} x {args.seconds:g} s synthetic 44.1 kHz mono clips "
+                         + ("in all, cut over the GPUs by window count" if args.scaling == "strong" else "per GPU")
+                         + f", {args.speakers} speakers, net 60-{H1}-{H2}-{C}"),
+            "scaling_conventions": "strong: --clips is the whole job's clip count (default); weak: --clips per GPU (--scaling weak)",
             "windows_per_gpu": n_win,
+            "windows_by_rank": windows_by_rank,
+            "windows_total": total_windows,
             "batch": "one optimiser step per epoch over all windows (gradients summed on device"
-                     + (", one in-place RCCL all-reduce of the gradient vector across ranks)"
+                     + (", one in-place all-reduce of the gradient vector across ranks)"
                         if (comm is not None or torch_rccl is not None) else ")"),
             "epochs_per_step": 1,
             "dropout": args.dropout,
             "lr": args.lr,
             "parallelism": f"files sharded over {world} GPU(s)",
+            "collective": ("none (one rank)" if not multi else "library host transport (ranks share a GPU: rehearsal)" if args.share_gpu
+                           else "library RCCL communicator, in place on the gradient vector" if comm is not None
+                           else "torch.distributed RCCL group (fallback)"),
             **({"collective_note": comm_note} if comm_note else {}),
         },
         "breakdown_ms": {"extract": t_ext_ms, "train_epoch": t_train_ms},

@@ -51,6 +51,8 @@ typedef struct szh_net szh_net;
 
 /* Select the HIP device this thread's later calls use (ordinal as in hipSetDevice). */
 int szh_init(int device_ordinal);
+/* Number of HIP devices this process can use (0 when there is none); does not select or initialise one. */
+int szh_device_count(void);
 /* Wait for everything this process has enqueued on the current device (call before exit or before
  * handing the device to another library; handles stay valid and are destroyed by their own calls). */
 int szh_shutdown(void);
@@ -287,6 +289,19 @@ int szh_net_vote_dev(szh_net *net, const float *feats_dev, uint64_t n, float thr
  * ranks by any host-side channel (pipe, file, environment).
  * szh_comm_create: collective over the `world` ranks (blocks until all have called), on the
  * current device.  world == 1 with id == NULL makes a communicator whose calls do nothing. */
+/* szh_shard_ranges: how the file list of main.rs:500-508 / lib.rs:643 is cut over `world` ranks: contiguous
+ * ranges in list order, balanced on window count.  n_windows[n_files] are the files' window counts; rank r
+ * takes files [out[r], out[r + 1]), out has world + 1 entries, out[0] = 0, out[world] = n_files.  Boundary r
+ * is the file index whose window prefix sum lies nearest to r / world of the total (the smaller index on a
+ * tie; never before the previous boundary), so ranks may receive no file when there are fewer files than
+ * ranks.  Pure host arithmetic: every rank computes the same cut without talking to the others. */
+int szh_shard_ranges(const uint64_t *n_windows, uint32_t n_files, uint32_t world, uint32_t *out);
+
+/* The transport of a communicator is fixed by its id.  szh_comm_unique_id draws an RCCL id unless the
+ * environment variable STREAMZ_COMM is "host": then the id names a shared-memory segment and the sums of
+ * that communicator are formed on the host (device -> shared memory, added in rank order, identical bits
+ * on every rank, -> device).  That transport is for ranks that share a GPU, where RCCL refuses to form a
+ * communicator (rehearsals of a multi-rank run on a smaller machine); vectors of up to 16 M floats. */
 #define SZH_COMM_ID_BYTES 128
 typedef struct szh_comm szh_comm;
 int szh_comm_unique_id(uint8_t id[SZH_COMM_ID_BYTES]);
@@ -343,6 +358,11 @@ int szh_load_cached_features(const char *path, szh_extractor *ext, float **feats
 /* WAV ingest alone (load_and_resample_file, lib.rs:509-529, wav arm at 44.1 kHz):
  * *pcm is malloc'd mono int16; release with szh_free. */
 int szh_wav_read(const char *path, int16_t **pcm, uint64_t *n_samples);
+
+/* Header of a WAV file without reading its samples: the number of mono sample frames szh_wav_read would
+ * return, the sample rate and the channel count (what hound's WavReader::duration / spec give the
+ * reference, lib.rs:517-518).  Host only.  Lets a rank size its share of a file list before decoding. */
+int szh_wav_info(const char *path, uint64_t *n_frames, uint32_t *sample_rate, uint16_t *channels);
 
 /* ---- measurement ----------------------------------------------------------------------- */
 /* No counterpart in the reference.  When enabled, every kernel launch of the extraction and

@@ -13,10 +13,10 @@ from ._capi import (Comm, comm_unique_id, extract_embedding, extract_embedding_f
                     identify_from_features, identify_speaker, identify_speaker_with_threshold,
                     identify_speaker_with_threshold_feats, identify_speaker_list, identify_speaker_list_dev,
                     lib, library_path, load_cached_features, pretrain_from_features, profile_enable,
-                    profile_report, train_from_feature_map, wav_read, window_count)
+                    profile_report, shard_ranges, train_from_feature_map, wav_info, wav_read, window_count)
 
 __all__ = ["Comm", "comm_unique_id", "extract_embedding", "extract_embedding_from_features", "median_embedding_from_features", "FEATURE_SIZE", "FeatureExtractor", "augment", "pretrain_network", "Plan", "SimpleNeuralNet", "StreamzError", "exported_symbols",
            "identify_from_features", "identify_speaker", "identify_speaker_with_threshold",
            "identify_speaker_with_threshold_feats", "identify_speaker_list", "identify_speaker_list_dev",
            "lib", "library_path", "load_cached_features", "pretrain_from_features", "profile_enable",
-           "profile_report", "train_from_feature_map", "wav_read", "window_count"]
+           "profile_report", "shard_ranges", "train_from_feature_map", "wav_info", "wav_read", "window_count"]

@@ -27,6 +27,7 @@ def library_path():
 _SIGS = {
     # name: (restype, argtypes)
     "szh_init": (C.c_int, [C.c_int]),
+    "szh_device_count": (C.c_int, []),
     "szh_shutdown": (C.c_int, []),
     "szh_last_error": (C.c_char_p, []),
     "szh_free": (None, [C.c_void_p]),
@@ -106,6 +107,8 @@ _SIGS = {
     "szh_net_load": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
     "szh_load_cached_features": (C.c_int, [C.c_char_p, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
     "szh_wav_read": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
+    "szh_wav_info": (C.c_int, [C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_uint16)]),
+    "szh_shard_ranges": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
     "szh_profile_enable": (C.c_int, [C.c_int]),
     "szh_profile_report": (C.c_int64, [C.c_void_p, C.c_uint64]),
 }
@@ -598,6 +601,21 @@ def wav_read(path):
     finally:
         lib().szh_free(ptr)
     return arr
+
+
+def wav_info(path):
+    """(mono sample frames, sample rate, channels) from the file's header alone"""
+    n, sr, ch = C.c_uint64(), C.c_uint32(), C.c_uint16()
+    _check(lib().szh_wav_info(os.fsencode(path), C.byref(n), C.byref(sr), C.byref(ch)))
+    return int(n.value), int(sr.value), int(ch.value)
+
+
+def shard_ranges(n_windows, world):
+    """szh_shard_ranges: world + 1 file indices; rank r takes files [out[r], out[r + 1])"""
+    nw = np.ascontiguousarray(n_windows, np.uint64)
+    out = np.zeros(world + 1, np.uint32)
+    _check(lib().szh_shard_ranges(_p(nw), nw.size, world, _p(out)))
+    return [int(v) for v in out]
 
 
 def profile_enable(on=True):

@@ -490,6 +490,12 @@ int szh_init(int device_ordinal)
     return noalloc_setup();
 }
 
+int szh_device_count(void)
+{
+    int n = 0;
+    return hipGetDeviceCount(&n) == hipSuccess && n > 0 ? n : 0;
+}
+
 int szh_shutdown(void)
 {
     // handles own all device memory; what is left is work still in flight on the device
@@ -1305,6 +1311,53 @@ int szh_wav_read(const char* path, int16_t** pcm, uint64_t* n_samples)
     *n_samples = mono.size();
     return SZH_OK;
     SZ_CATCH
+}
+
+int szh_wav_info(const char* path, uint64_t* n_frames, uint32_t* sample_rate, uint16_t* channels)
+{
+    SZ_TRY
+    if (!path || !n_frames) { set_error("null argument"); return SZH_EINVAL; }
+    if (!ends_with_ci(path, ".wav")) { set_error("Unsupported format: %s (only 16-bit PCM WAV is handled on this path)", path); return SZH_EFORMAT; }
+    WavInfo info;
+    uint64_t frames = 0;
+    std::string err;
+    if (!wav_probe(path, info, frames, err)) { set_error("%s", err.c_str()); return SZH_EIO; }
+    *n_frames = frames;
+    if (sample_rate) *sample_rate = info.sample_rate;
+    if (channels) *channels = info.channels;
+    return SZH_OK;
+    SZ_CATCH
+}
+
+int szh_shard_ranges(const uint64_t* n_windows, uint32_t n_files, uint32_t world, uint32_t* out)
+{
+    if (!out || world == 0 || (n_files && !n_windows)) { set_error("bad argument"); return SZH_EINVAL; }
+    typedef unsigned __int128 u128;
+    u128 total = 0;
+    for (uint32_t f = 0; f < n_files; ++f) total += n_windows[f];
+    out[0] = 0;
+    uint32_t b = 0;   // boundary of the previous rank
+    u128 prefix = 0;  // windows of files [0, b)
+    for (uint32_t r = 1; r < world; ++r) {
+        if (total == 0) { out[r] = (uint32_t)((uint64_t)n_files * r / world); continue; }  // nothing to balance on: by count
+        const u128 target = total * r;  // compared with prefix * world
+        // The prefix sums do not decrease, so the nearest one is the last below the target or the first at
+        // or above it.  `low` is the first index (from b on) that has the last prefix sum below the target.
+        uint32_t i = b, low = b;
+        u128 p = prefix, p_low = prefix;
+        bool have_low = false;
+        while (p * world < target) {  // ends by i == n_files: the whole list's sum times world is >= target
+            if (!have_low || p != p_low) { low = i; p_low = p; have_low = true; }
+            p += n_windows[i];
+            ++i;
+        }
+        if (have_low && target - p_low * world <= p * world - target) { i = low; p = p_low; }
+        b = i;
+        prefix = p;
+        out[r] = b;
+    }
+    out[world] = n_files;
+    return SZH_OK;
 }
 
 int szh_load_cached_features(const char* path, szh_extractor* ext, float** feats, uint64_t* n_windows)

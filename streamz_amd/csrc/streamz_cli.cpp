@@ -11,10 +11,16 @@
 //   --eval           scores target_files.txt against the embeddings saved in model.npz
 //                    (main.rs:522-625); nothing is trained or written
 //   --gpus N         (no counterpart in the reference) the initial training pass runs on N GPUs, one
-//                    process each: the labelled files are sharded over the ranks and every epoch is one
-//                    optimiser step over all windows with one RCCL all-reduce of the gradients
-//                    (szh_net_train_epochs_sharded) instead of the per-file batches of 8 of
-//                    train_from_feature_map.  The labelling pass then runs on the first GPU.
+//                    process each: the labelled files are cut into contiguous ranges balanced on window
+//                    count (szh_shard_ranges), every rank decodes and extracts only its own range, and
+//                    every epoch is one optimiser step over all windows with one RCCL all-reduce of the
+//                    gradients (szh_net_train_epochs_sharded) instead of the per-file batches of 8 of
+//                    train_from_feature_map: 100 optimiser steps in all where the reference takes
+//                    100 x windows / 8 per file, so the model of this pass is far less trained than the
+//                    reference's -- it is the throughput schedule, not a replacement for the default one.
+//                    The labelling pass then runs on the first GPU (which extracts the remaining files).
+//   --share-gpu      with --gpus: the ranks take the GPUs round-robin and sum on the host (a rehearsal of
+//                    the multi-rank flow on a machine with fewer GPUs than ranks)
 //
 // Not handled here (outside the accelerated path): MP3 input and cache/*.wav,
 // --encode / --decode / --checksum.  The reference processes the second pass under a
@@ -31,6 +37,8 @@
 #include <string>
 #include <vector>
 
+#include <poll.h>
+#include <signal.h>
 #include <sys/stat.h>
 #include <sys/wait.h>
 #include <unistd.h>
@@ -224,25 +232,131 @@ int run_eval(const std::vector<Entry>& train_files, const std::vector<Entry>& ta
     return 0;
 }
 
-// The initial pass on `world` ranks (this process is `rank`; ranks > 0 are forked children that end
-// here).  id_fd: where a child reads the communicator id; id_out: where rank 0 writes it.
-float sharded_initial_pass(SimpleNeuralNet& net, const std::vector<std::pair<std::string, size_t>>& refs,
-                           const std::map<std::string, Features>& feature_map, int rank, int world, int id_fd,
-                           const std::vector<int>& id_out, uint64_t seed)
+// The ranks of --gpus N: this process is rank 0, the others are forked children.  Two pipes per child: the
+// child reports over one that it is ready (device selected, its files extracted) or that it failed, and
+// receives the communicator id over the other.  Every way out of main reaps the children.
+struct Ranks {
+    int rank = 0, world = 1;
+    int id_in = -1, status_out = -1;       // a child's ends
+    std::vector<int> id_out, status_in;     // rank 0's ends, one per child
+    std::vector<pid_t> children;
+    std::vector<bool> reaped;
+
+    void spawn(int n)
+    {
+        world = n;
+        ::signal(SIGPIPE, SIG_IGN);  // a rank that died shows as a failed write, not as a signal
+        for (int r = 1; r < world && rank == 0; ++r) {
+            int to_child[2], from_child[2];
+            if (::pipe(to_child) != 0 || ::pipe(from_child) != 0) throw Error(SZH_EINVAL, "pipe failed");
+            std::fflush(nullptr);
+            const pid_t pid = ::fork();
+            if (pid < 0) throw Error(SZH_EINVAL, "fork failed");
+            if (pid == 0) {
+                rank = r; id_in = to_child[0]; status_out = from_child[1];
+                ::close(to_child[1]); ::close(from_child[0]);
+                for (int fd : id_out) ::close(fd);
+                for (int fd : status_in) ::close(fd);
+                id_out.clear(); status_in.clear(); children.clear(); reaped.clear();
+                if (!std::freopen("/dev/null", "w", stdout)) {}  // messages come from rank 0 only
+            } else {
+                ::close(to_child[0]); ::close(from_child[1]);
+                id_out.push_back(to_child[1]); status_in.push_back(from_child[0]);
+                children.push_back(pid); reaped.push_back(false);
+            }
+        }
+    }
+    // a child: tell rank 0 how the set-up went
+    void report(char status) { if (status_out >= 0 && ::write(status_out, &status, 1) != 1) {} }
+    // rank 0: every child must report 'R'; a child that exits or stays silent for ten minutes is a failure
+    void await_ready()
+    {
+        for (size_t c = 0; c < children.size(); ++c) {
+            char st = 0;
+            for (int waited_ms = 0;; waited_ms += 200) {
+                struct pollfd pf = {status_in[c], POLLIN, 0};
+                const int pr = ::poll(&pf, 1, 200);
+                if (pr > 0) { if (::read(status_in[c], &st, 1) != 1) st = 0; break; }
+                int status = 0;
+                if (::waitpid(children[c], &status, WNOHANG) == children[c]) { reaped[c] = true; break; }
+                if (waited_ms > 600000) break;
+            }
+            if (st != 'R') throw Error(SZH_EINVAL, "rank " + std::to_string(c + 1) + " of --gpus did not come up (see its messages above)");
+        }
+    }
+    // rank 0 after the pass: all children must have ended well
+    void join()
+    {
+        for (int fd : id_out) ::close(fd);
+        id_out.clear();
+        bool ok = true;
+        for (size_t c = 0; c < children.size(); ++c) {
+            if (reaped[c]) { ok = false; continue; }
+            int status = 0;
+            if (::waitpid(children[c], &status, 0) < 0 || !WIFEXITED(status) || WEXITSTATUS(status) != 0) ok = false;
+            reaped[c] = true;
+        }
+        if (!ok) throw Error(SZH_EINVAL, "a rank of the initial pass failed");
+    }
+    ~Ranks()
+    {
+        for (int fd : id_out) ::close(fd);  // a child still waiting for the id sees the end of the pipe and leaves
+        for (int fd : status_in) ::close(fd);
+        for (size_t c = 0; c < children.size(); ++c) {
+            if (reaped[c]) continue;
+            int status = 0;
+            if (::waitpid(children[c], &status, WNOHANG) == 0) {  // still running on an exit path that did not join: stop it
+                ::kill(children[c], SIGTERM);
+                ::waitpid(children[c], &status, 0);
+            }
+        }
+    }
+};
+
+// decode + extract the listed paths into feature_map (batch_resample, lib.rs:541-547: unreadable files are
+// dropped; then the file-parallel extraction loop, main.rs:500-508)
+void extract_into(const FeatureExtractor& extractor, const std::vector<std::string>& paths, std::map<std::string, Features>& feature_map)
+{
+    auto audio = batch_resample(paths);
+    std::vector<std::vector<int16_t>> clips;
+    for (auto& a : audio) clips.push_back(std::move(a.second));
+    std::vector<Features> feats = extractor.extract_batch(clips);
+    for (size_t i = 0; i < audio.size(); ++i) feature_map[audio[i].first] = std::move(feats[i]);
+}
+
+// this rank's contiguous range of the labelled files, balanced on the window counts their headers give
+std::pair<size_t, size_t> rank_range(const std::vector<std::pair<std::string, size_t>>& refs, int rank, int world)
+{
+    std::vector<uint64_t> windows(refs.size(), 0);
+    for (size_t f = 0; f < refs.size(); ++f) {
+        uint64_t frames = 0;
+        uint32_t rate = 0;
+        if (szh_wav_info(refs[f].first.c_str(), &frames, &rate, nullptr) == SZH_OK && rate == DEFAULT_SAMPLE_RATE)
+            windows[f] = szh_window_count(frames);  // a file that cannot be read brings no windows (and is skipped later)
+    }
+    std::vector<uint32_t> cut((size_t)world + 1);
+    check(szh_shard_ranges(windows.data(), (uint32_t)refs.size(), (uint32_t)world, cut.data()));
+    return {cut[(size_t)rank], cut[(size_t)rank + 1]};
+}
+
+// The initial pass of one rank over files [lo, hi) of refs.
+float sharded_initial_pass(SimpleNeuralNet& net, const std::vector<std::pair<std::string, size_t>>& refs, size_t lo, size_t hi,
+                           const std::map<std::string, Features>& feature_map, Ranks& ranks, uint64_t seed)
 {
     uint8_t id[SZH_COMM_ID_BYTES];
-    if (rank == 0) {
+    if (ranks.rank == 0) {
+        ranks.await_ready();
         check(szh_comm_unique_id(id));
-        for (int fd : id_out)
+        for (int fd : ranks.id_out)
             if (::write(fd, id, sizeof(id)) != (ssize_t)sizeof(id)) throw Error(SZH_EINVAL, "could not hand the communicator id to a rank");
-    } else if (::read(id_fd, id, sizeof(id)) != (ssize_t)sizeof(id)) {
-        throw Error(SZH_EINVAL, "no communicator id from rank 0");
+    } else {
+        ranks.report('R');
+        if (::read(ranks.id_in, id, sizeof(id)) != (ssize_t)sizeof(id)) throw Error(SZH_EINVAL, "no communicator id from rank 0");
     }
     szh_comm* comm = nullptr;
-    check(szh_comm_create(id, rank, world, &comm));
+    check(szh_comm_create(id, ranks.rank, ranks.world, &comm));
+    struct CommGuard { szh_comm* c; ~CommGuard() { szh_comm_destroy(c); } } guard{comm};
     check(szh_net_broadcast_params_dev(net.handle(), comm, 0, nullptr));
-    // contiguous runs of the labelled files, in list order
-    const size_t lo = refs.size() * (size_t)rank / (size_t)world, hi = refs.size() * (size_t)(rank + 1) / (size_t)world;
     std::vector<float> x;
     std::vector<int32_t> labels;
     for (size_t f = lo; f < hi; ++f) {
@@ -254,7 +368,6 @@ float sharded_initial_pass(SimpleNeuralNet& net, const std::vector<std::pair<std
     float loss = 0.0f;
     check(szh_net_train_epochs_sharded(net.handle(), comm, x.data(), labels.data(), labels.size(), (uint32_t)TRAIN_EPOCHS, 0.01f,
                                        DROPOUT_PROB, seed, &loss));
-    szh_comm_destroy(comm);
     return loss;
 }
 
@@ -262,6 +375,7 @@ float sharded_initial_pass(SimpleNeuralNet& net, const std::vector<std::pair<std
 
 int main(int argc, char** argv)
 {
+    Ranks ranks;  // outlives everything below: its destructor reaps the forked ranks on every way out
     try {
         float conf_threshold = DEFAULT_CONF_THRESHOLD;
         bool have_burn = false;
@@ -270,40 +384,16 @@ int main(int argc, char** argv)
         uint64_t seed = 0x5EEDull;
         if ((idx = find_arg(argc, argv, "--seed")) >= 0 && idx + 1 < argc) seed = std::strtoull(argv[idx + 1], nullptr, 10);
         const bool eval_mode = find_arg(argc, argv, "--eval") >= 0;  // main.rs:350
-        // --gpus N: the ranks are separate processes, forked before anything touches a GPU
-        int world = 1, rank = 0, id_fd = -1;
-        std::vector<int> id_out;
-        std::vector<pid_t> children;
-        bool sharded = false;  // --gpus given (1 is allowed: the same schedule on one rank)
-        if ((idx = find_arg(argc, argv, "--gpus")) >= 0 && idx + 1 < argc) { world = std::max(1, std::atoi(argv[idx + 1])); sharded = true; }
-        if (sharded && (eval_mode || exists(MODEL_PATH))) {
-            std::fprintf(stderr, "--gpus only spreads the initial training pass, which this run does not make; using one GPU\n");
-            world = 1;
-            sharded = false;
-        }
-        for (int r = 1; r < world && rank == 0; ++r) {
-            int fd[2];
-            if (::pipe(fd) != 0) throw Error(SZH_EINVAL, "pipe failed");
-            std::fflush(stdout);
-            const pid_t pid = ::fork();
-            if (pid < 0) throw Error(SZH_EINVAL, "fork failed");
-            if (pid == 0) {
-                rank = r; id_fd = fd[0]; ::close(fd[1]);
-                for (int w : id_out) ::close(w);
-                id_out.clear(); children.clear();
-            } else {
-                ::close(fd[0]); id_out.push_back(fd[1]); children.push_back(pid);
-            }
-        }
-        if (sharded) check(szh_init(rank));
-        else if ((idx = find_arg(argc, argv, "--device")) >= 0 && idx + 1 < argc) check(szh_init(std::atoi(argv[idx + 1])));
         for (const char* flag : {"--encode", "--decode", "--checksum"})
             if (find_arg(argc, argv, flag) >= 0) {
                 std::fprintf(stderr, "%s is not part of the accelerated path and is not handled by this binary\n", flag);
                 return 2;
             }
-        FeatureExtractor extractor;
+        int device = -1;
+        if ((idx = find_arg(argc, argv, "--device")) >= 0 && idx + 1 < argc) device = std::atoi(argv[idx + 1]);
         if (find_arg(argc, argv, "--check-embeddings") >= 0) {  // main.rs:357-366
+            if (device >= 0) check(szh_init(device));
+            FeatureExtractor extractor;
             try {
                 SimpleNeuralNet net = SimpleNeuralNet::load(MODEL_PATH);
                 std::printf("Loaded %s for embedding check\n", MODEL_PATH);
@@ -335,8 +425,49 @@ int main(int argc, char** argv)
             return 0;
         }
         const std::vector<Entry> original = train_files;
+        const bool model_exists = exists(MODEL_PATH);
 
-        // decode once (main.rs:486-490), then the file-parallel extraction loop (main.rs:500-508)
+        // --gpus N: the ranks are separate processes, forked here: after every early way out above, before
+        // anything touches a GPU
+        int world = 1;
+        bool sharded = false;  // --gpus given (1 is allowed: the same schedule on one rank)
+        const bool share_gpu = find_arg(argc, argv, "--share-gpu") >= 0;
+        if ((idx = find_arg(argc, argv, "--gpus")) >= 0 && idx + 1 < argc) { world = std::max(1, std::atoi(argv[idx + 1])); sharded = true; }
+        if (sharded && (eval_mode || model_exists)) {
+            std::fprintf(stderr, "--gpus only spreads the initial training pass, which this run does not make; using one GPU\n");
+            world = 1;
+            sharded = false;
+        }
+        if (sharded && share_gpu && world > 1) ::setenv("STREAMZ_COMM", "host", 1);  // RCCL refuses ranks that share a device
+        if (sharded) ranks.spawn(world);
+        const int rank = ranks.rank;
+        try {
+            if (sharded) {
+                // (devices are counted here, after the fork: no GPU state crosses it)
+                const int n_dev = share_gpu ? std::max(1, szh_device_count()) : 1;
+                check(szh_init(share_gpu ? rank % n_dev : rank));
+            } else if (device >= 0) {
+                check(szh_init(device));
+            }
+        } catch (const Error&) {
+            ranks.report('F');
+            throw;
+        }
+        FeatureExtractor extractor;
+
+        size_t num_speakers = count_speakers(train_files);  // main.rs:627-650
+        if (!eval_mode && !model_exists && num_speakers == 0) {
+            num_speakers = 1;
+            train_files[0].labelled = true;
+            train_files[0].cls = 0;
+            std::printf("No labeled speakers found \xe2\x80\x94 assigned speaker 0 to first file.\n");
+        }
+        std::vector<std::pair<std::string, size_t>> refs;  // the labelled files, in list order (main.rs:653-657)
+        for (const Entry& e : train_files)
+            if (e.labelled) refs.emplace_back(e.path, e.cls);
+
+        // decode once (main.rs:486-490), then the file-parallel extraction loop (main.rs:500-508); with --gpus
+        // a rank takes only its own range of the labelled files, and rank 0 the rest after the initial pass
         std::vector<std::string> path_list;
         for (const Entry& e : train_files) path_list.push_back(e.path);
         std::vector<Entry> target_files;
@@ -344,24 +475,33 @@ int main(int argc, char** argv)
             for (const Entry& e : load_train_files(TARGET_FILE_LIST))
                 if (e.labelled) { target_files.push_back(e); path_list.push_back(e.path); }
         }
-        auto audio = batch_resample(path_list);
-        std::vector<std::vector<int16_t>> clips;
-        for (auto& a : audio) clips.push_back(std::move(a.second));
-        std::vector<Features> feats = extractor.extract_batch(clips);
         std::map<std::string, Features> feature_map;
-        for (size_t i = 0; i < audio.size(); ++i) feature_map[audio[i].first] = std::move(feats[i]);
-        for (const Entry& e : train_files)
-            if (!feature_map.count(e.path)) std::fprintf(stderr, "No features found for training path: %s\n", e.path.c_str());
+        std::pair<size_t, size_t> range{0, refs.size()};
+        try {
+            if (sharded) {
+                range = rank_range(refs, rank, world);
+                std::vector<std::string> mine;
+                for (size_t f = range.first; f < range.second; ++f) mine.push_back(refs[f].first);
+                extract_into(extractor, mine, feature_map);
+            } else {
+                extract_into(extractor, path_list, feature_map);
+            }
+        } catch (const Error&) {
+            ranks.report('F');
+            throw;
+        }
 
         const size_t dataset_size = train_files.size();  // main.rs:517-519
         size_t burn_default = (size_t)std::ceil((float)dataset_size * DEFAULT_BURN_IN_FRAC);
         burn_default = std::min<size_t>(std::max<size_t>(burn_default, 10), 50);
         const size_t burn_in_limit_val = have_burn ? burn_in_limit : burn_default;
 
-        if (eval_mode) return run_eval(train_files, target_files, feature_map, conf_threshold);
+        if (eval_mode) {
+            for (const Entry& e : train_files)
+                if (!feature_map.count(e.path)) std::fprintf(stderr, "No features found for training path: %s\n", e.path.c_str());
+            return run_eval(train_files, target_files, feature_map, conf_threshold);
+        }
 
-        size_t num_speakers = count_speakers(train_files);  // main.rs:627-650
-        const bool model_exists = exists(MODEL_PATH);
         SimpleNeuralNet net = [&]() -> SimpleNeuralNet {
             if (model_exists) {
                 try {
@@ -371,37 +511,34 @@ int main(int argc, char** argv)
                     return n;
                 } catch (const Error& e) {
                     std::fprintf(stderr, "Failed to load model: %s\n", e.what());
-                    return SimpleNeuralNet(FEATURE_SIZE, 512, 256, std::max<size_t>(num_speakers, 1), seed);
                 }
-            }
-            if (num_speakers == 0) {
-                num_speakers = 1;
-                train_files[0].labelled = true;
-                train_files[0].cls = 0;
-                std::printf("No labeled speakers found \xe2\x80\x94 assigned speaker 0 to first file.\n");
             }
             return SimpleNeuralNet(FEATURE_SIZE, 512, 256, std::max<size_t>(num_speakers, 1), seed);
         }();
 
         if (!model_exists) {  // main.rs:652-669
-            std::vector<std::pair<std::string, size_t>> refs;
-            for (const Entry& e : train_files)
-                if (e.labelled) refs.emplace_back(e.path, e.cls);
             if (sharded) {
-                const float loss = sharded_initial_pass(net, refs, feature_map, rank, world, id_fd, id_out, seed);
-                if (rank != 0) { std::fflush(nullptr); ::_exit(0); }  // a rank's part ends with the initial pass
-                for (int fd : id_out) ::close(fd);
-                for (pid_t pid : children) {
-                    int status = 0;
-                    if (::waitpid(pid, &status, 0) < 0 || !WIFEXITED(status) || WEXITSTATUS(status) != 0)
-                        throw Error(SZH_EINVAL, "a rank of the initial pass failed");
+                const float loss = sharded_initial_pass(net, refs, range.first, range.second, feature_map, ranks, seed);
+                if (rank != 0) {  // a rank's part ends with the initial pass
+                    check(szh_shutdown());
+                    return 0;
                 }
+                ranks.join();
                 std::printf("Initial training loss: %.4f  (%d GPU%s, one optimiser step per epoch)\n", loss, world, world > 1 ? "s" : "");
+                // the labelling pass runs here alone and walks every file: extract what the other ranks held
+                std::vector<std::string> rest;
+                for (const std::string& p : path_list)
+                    if (!feature_map.count(p)) rest.push_back(p);
+                extract_into(extractor, rest, feature_map);
+                for (const auto& fc : refs)  // as train_from_feature_map does for every file it trained on (lib.rs:655)
+                    if (feature_map.count(fc.first)) net.record_training_file(fc.second, fc.first);
             } else if (!refs.empty()) {
                 const float loss = train_from_feature_map(net, feature_map, refs, TRAIN_EPOCHS, 0.01f, DROPOUT_PROB, BATCH_SIZE, seed);
                 std::printf("Initial training loss: %.4f\n", loss);
             }
         }
+        for (const Entry& e : train_files)
+            if (!feature_map.count(e.path)) std::fprintf(stderr, "No features found for training path: %s\n", e.path.c_str());
 
         // second pass, main.rs:710-835
         std::map<size_t, std::vector<std::vector<float>>> speaker_features;

@@ -57,6 +57,48 @@ bool wav_read_raw(const std::string& path, std::vector<int16_t>& samples, WavInf
     return false;
 }
 
+bool wav_probe(const std::string& path, WavInfo& info, uint64_t& n_frames, std::string& err)
+{
+    FILE* f = std::fopen(path.c_str(), "rb");
+    if (!f) { err = "cannot open " + path; return false; }
+    struct Closer { FILE* f; ~Closer() { std::fclose(f); } } closer{f};
+    std::fseek(f, 0, SEEK_END);
+    const long size = std::ftell(f);
+    std::fseek(f, 0, SEEK_SET);
+    uint8_t h[40];
+    if (size < 12 || std::fread(h, 1, 12, f) != 12 || std::memcmp(h, "RIFF", 4) != 0 || std::memcmp(h + 8, "WAVE", 4) != 0) {
+        err = path + ": not a RIFF/WAVE file";
+        return false;
+    }
+    long pos = 12;
+    bool have_fmt = false;
+    uint16_t tag = 0;
+    while (pos + 8 <= size) {
+        if (std::fseek(f, pos, SEEK_SET) != 0 || std::fread(h, 1, 8, f) != 8) break;
+        const uint32_t clen = rd32(h + 4);
+        const uint64_t avail = (uint64_t)(size - (pos + 8));
+        if (std::memcmp(h, "fmt ", 4) == 0) {
+            const size_t want = clen >= 26 && avail >= 26 ? 26 : 16;
+            if (clen < 16 || avail < 16 || std::fread(h, 1, want, f) != want) { err = path + ": short fmt chunk"; return false; }
+            tag = rd16(h);
+            info.channels = rd16(h + 2);
+            info.sample_rate = rd32(h + 4);
+            info.bits = rd16(h + 14);
+            if (tag == 0xFFFE && want == 26) tag = rd16(h + 24);
+            have_fmt = true;
+        } else if (std::memcmp(h, "data", 4) == 0) {
+            if (!have_fmt) { err = path + ": data chunk before fmt chunk"; return false; }
+            if (tag != 1 || info.bits != 16 || info.channels == 0) { err = path + ": only 16-bit integer PCM is supported"; return false; }
+            const uint64_t samples = ((uint64_t)clen <= avail ? (uint64_t)clen : avail) / 2;
+            n_frames = info.channels <= 1 ? samples : (samples + info.channels - 1) / info.channels;  // downmix keeps a ragged last frame
+            return true;
+        }
+        pos += 8 + (long)clen + (long)(clen & 1);
+    }
+    err = path + ": no data chunk";
+    return false;
+}
+
 std::vector<int16_t> downmix_to_mono(const std::vector<int16_t>& samples, size_t channels)
 {
     if (channels <= 1) return samples;

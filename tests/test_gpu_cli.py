@@ -326,3 +326,75 @@ def test_cli_gpus_option_runs_the_epoch_synchronous_initial_pass(sz, tmp_path):
     # a saved model means no initial pass: the option is refused with a note, the run goes on
     r2 = subprocess.run([CLI, "--seed", "21", "--gpus", "2"], cwd=tmp_path, capture_output=True, text=True, timeout=900)
     assert r2.returncode == 0 and "using one GPU" in r2.stderr
+
+
+def test_cli_two_ranks_on_one_gpu_shard_by_windows_and_match_a_replay(sz, tmp_path):
+    """--gpus 2 --share-gpu: two forked ranks (both on device 0, sums on the host transport of the library's
+    communicator), each decoding and extracting only its own range of the labelled files -- ranges balanced
+    on window count, not on file count -- then the labelling pass on rank 0.  The printed loss is replayed
+    here with two nets that stand for the ranks."""
+    import re
+    import torch
+    from helpers import grad_view
+    os.makedirs(tmp_path / "wav")
+    seconds = [6.0, 1.0, 1.0, 1.0, 1.0, 2.0]     # by file count the cut would be 3 | 3; by windows it is 1 | 5
+    clips, lines = [], []
+    for i, sec in enumerate(seconds):
+        pcm = synth(i % 2, 120 + i, seconds=sec)
+        write_wav(str(tmp_path / "wav" / f"s{i}.wav"), pcm)
+        clips.append(pcm)
+        lines.append(f"wav/s{i}.wav,{i % 2}")
+    (tmp_path / "train_files.txt").write_text("\n".join(lines) + "\nwav/absent.wav,1\n")
+    r = subprocess.run([CLI, "--seed", "33", "--gpus", "2", "--share-gpu"], cwd=tmp_path, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr
+    m = re.search(r"Initial training loss: ([0-9.]+)  \(2 GPUs, one optimiser step per epoch\)", r.stdout)
+    assert m, r.stdout
+    assert r.stdout.count("Initial training loss") == 1            # messages come from rank 0 only
+    assert "No features found for training path: wav/absent.wav" in r.stderr
+    # ---- the replay
+    ext = sz.FeatureExtractor()
+    feats = [ext.extract(c) for c in clips]
+    cut = sz.shard_ranges([len(f) for f in feats] + [0], 2)        # the absent file brings no windows
+    assert cut == [0, 1, 7]
+    nets = [sz.SimpleNeuralNet(60, 512, 256, 2, seed=33) for _ in range(2)]
+    shards = []
+    for a, b in zip(cut, cut[1:]):
+        idx = [i for i in range(a, min(b, len(feats)))]
+        x = np.concatenate([feats[i] for i in idx])
+        lab = np.concatenate([np.full(len(feats[i]), i % 2, np.int32) for i in idx])
+        shards.append((torch.from_numpy(x).cuda(), torch.from_numpy(lab).cuda()))
+    for ep in range(100):
+        for net, (dx, dl) in zip(nets, shards):
+            net.zero_grad_dev(0)
+            net.accumulate_dev(dx.data_ptr(), dl.data_ptr(), dx.shape[0], 0.2, 33 + ep, 0)
+        torch.cuda.synchronize()
+        total = grad_view(nets[0]) + grad_view(nets[1])          # slot 0 + slot 1, as the host transport adds them
+        tail = total[-2:].cpu().numpy()
+        for net in nets:
+            grad_view(net).copy_(total)
+            net.apply_grad_dev(0.01, 0)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(nets[0].get_flat(), nets[1].get_flat())
+    assert abs(float(m.group(1)) - float(tail[0] / tail[1])) < 1e-4
+    assert (tmp_path / "train_files.txt").read_text().splitlines() == lines + ["wav/absent.wav,1"]
+    z = np.load(tmp_path / "model.npz")
+    assert int(z["num_speakers"][0]) == 2
+    assert bytes(z["speaker_0_files"]).decode().split("\n") == ["wav/s0.wav", "wav/s2.wav", "wav/s4.wav"]
+    for i in (0, 5):   # rank 0 held file 0 only and extracted the others after the initial pass
+        np.testing.assert_array_equal(np.load(tmp_path / "feature_cache" / f"wav_s{i}.wav.npy"), feats[i])
+
+
+def test_cli_rank_that_cannot_come_up_ends_the_run_with_a_message(tmp_path):
+    """--gpus 2 without --share-gpu on a one-GPU box: rank 1 finds no device 1.  Rank 0 must neither hang in
+    the communicator's rendezvous nor die silently: it reports the rank, reaps it, and exits non-zero."""
+    import torch
+    if torch.cuda.device_count() > 1:
+        pytest.skip("needs a machine with a single GPU")
+    os.makedirs(tmp_path / "wav")
+    for i in range(2):
+        write_wav(str(tmp_path / "wav" / f"f{i}.wav"), synth(i, 140 + i, seconds=1.0))
+    (tmp_path / "train_files.txt").write_text("wav/f0.wav,0\nwav/f1.wav,1\n")
+    r = subprocess.run([CLI, "--gpus", "2"], cwd=tmp_path, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 1
+    assert "rank 1 of --gpus did not come up" in r.stderr and "device ordinal 1 out of range" in r.stderr
+    assert not os.path.exists(tmp_path / "model.npz")

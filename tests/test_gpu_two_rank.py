@@ -2,7 +2,8 @@
 through the product's own device entry points, on the one GPU a test box has:
   * two nets in one process, each accumulating half of the rows, their gradient vectors
     (loss / live-row tail included) summed as the all-reduce does;
-  * two processes sharing device 0, gloo standing in for RCCL (which refuses two ranks on one GPU);
+  * two processes sharing device 0, gloo standing in for RCCL (which refuses two ranks on one GPU), and the
+    same two processes through the library's own communicator on its host transport;
   * the library's RCCL communicator with a single rank (dlopen, ncclCommInitRank, in-place
     ncclAllReduce / ncclBroadcast on library-owned memory);
   * bench.py's multi-rank branch, rehearsed with two ranks on one GPU and with RCCL at one rank.
@@ -119,6 +120,32 @@ def test_two_rank_processes_on_one_gpu(tmp_path):
     np.testing.assert_allclose(r0["params"], want, atol=1e-5)
 
 
+def test_two_rank_processes_through_the_library_host_transport(tmp_path):
+    """The same two processes with the sum done by szh_net_allreduce_grad_dev on a communicator whose id
+    names a shared-memory segment (STREAMZ_COMM=host): rank 0 == rank 1 bit for bit, and both equal the
+    gloo run's result."""
+    import two_rank_child as tr
+    env = dict(os.environ, WORLD_SIZE="2", STREAMZ_COMM="host", TWO_RANK_LIBRARY_COMM=str(tmp_path / "comm.id"))
+    procs = [subprocess.Popen([sys.executable, "-X", "faulthandler", os.path.join(ROOT, "tests", "two_rank_child.py"), str(tmp_path)],
+                              env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o[-4000:]
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    np.testing.assert_array_equal(r0["summed"], r1["summed"])
+    np.testing.assert_array_equal(r0["params"], r1["params"])
+    np.testing.assert_array_equal(r0["local"] + r1["local"], r0["summed"])   # rank order: slot 0 + slot 1, in f32
+    import streamz_amd as sz
+    params, files, labels = tr.make_data()
+    whole = sz.SimpleNeuralNet(*tr.DIMS, init=params)
+    _, summed = tr.epoch(whole, files, labels, range(len(files)))
+    assert r0["summed"][-1] == summed[-1]
+    np.testing.assert_allclose(r0["summed"][:-2], summed[:-2], atol=2e-6 * np.abs(summed[:-2]).max())
+    np.testing.assert_allclose(r0["params"], whole.get_flat(), atol=1e-6)
+    assert not os.path.exists("/dev/shm/" + open(tmp_path / "comm.id", "rb").read()[8:].split(b"\0")[0].decode().lstrip("/"))
+
+
 def test_rccl_communicator_single_rank_in_place():
     import torch
     import streamz_amd as sz
@@ -168,25 +195,35 @@ def _bench_line(cmd, env):
 
 
 def test_bench_multi_rank_branch():
-    small = ["--clips", "6", "--seconds", "5", "--steps", "2", "--warmup", "1", "--no-extras", "--no-cpu-baseline"]
+    # (no dropout: its mask is keyed by a rank's own row numbers, so only without it do two ranks repeat one rank's sums)
+    small = ["--clips", "6", "--seconds", "5", "--steps", "2", "--warmup", "1", "--no-extras", "--no-cpu-baseline", "--dropout", "0"]
     one = _bench_line([sys.executable, "bench.py", "--gpus", "1"] + small, dict(os.environ))
-    # two ranks on the one GPU (gradient vectors summed on the host)
-    two = _bench_line(lambda port: [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                                    "--master-addr", "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "2",
-                                    "--share-gpu"] + small, dict(os.environ))
-    assert two["n_gpus"] == 2 and two["config"]["windows_per_gpu"] == one["config"]["windows_per_gpu"]
-    assert two["mean_loss_last_step"] is not None and np.isfinite(two["mean_loss_last_step"])
+    assert one["scaling"] == "strong" and one["config"]["windows_by_rank"] == [one["config"]["windows_total"]]
+    # two ranks on the one GPU (the library's communicator on its host transport); strong scaling: the same
+    # six clips cut in two by window count, so the summed loss is that of the single-rank run
+    torchrun = lambda port: [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",  # noqa: E731
+                             "--master-addr", "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "2", "--share-gpu"]
+    two = _bench_line(lambda port: torchrun(port) + small, dict(os.environ))
+    assert two["n_gpus"] == 2 and two["scaling"] == "strong" and "host transport" in two["config"]["collective"]
+    assert two["config"]["windows_total"] == one["config"]["windows_total"]
+    assert two["config"]["windows_by_rank"] == [one["config"]["windows_total"] // 2] * 2
+    assert abs(two["mean_loss_last_step"] - one["mean_loss_last_step"]) < 1e-4 * one["mean_loss_last_step"]
+    # weak scaling: every rank brings its own six clips
+    weak = _bench_line(lambda port: torchrun(port) + small + ["--scaling", "weak"], dict(os.environ))
+    assert weak["scaling"] == "weak" and weak["config"]["windows_by_rank"] == [one["config"]["windows_total"]] * 2
+    assert weak["mean_loss_last_step"] is not None and np.isfinite(weak["mean_loss_last_step"])
     # the RCCL branch with a single rank: same numbers as the plain single-GPU run
     rccl = _bench_line([sys.executable, "bench.py", "--gpus", "1"] + small,
                        lambda port: dict(os.environ, BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                                          RANK="0", WORLD_SIZE="1", LOCAL_RANK="0"))
-    assert "RCCL" in rccl["config"]["batch"] and "collective_note" not in rccl["config"]
+    # (a line that carries collective_note did NOT run the library's collective: that counts as a failure here)
+    assert "library RCCL" in rccl["config"]["collective"] and "collective_note" not in rccl["config"]
     assert rccl["mean_loss_last_step"] == one["mean_loss_last_step"]
     # the stand-in for a library communicator that does not come up: torch's RCCL group on the same vector
     alt = _bench_line([sys.executable, "bench.py", "--gpus", "1"] + small,
                       lambda port: dict(os.environ, BENCH_FORCE_DIST="1", BENCH_FORCE_TORCH_RCCL="1", MASTER_ADDR="127.0.0.1",
                                         MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0"))
-    assert "torch.distributed RCCL group" in alt["config"]["collective_note"]
+    assert "torch.distributed RCCL group" in alt["config"]["collective_note"] and "fallback" in alt["config"]["collective"]
     assert alt["mean_loss_last_step"] == one["mean_loss_last_step"]
 
 

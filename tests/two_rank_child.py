@@ -32,10 +32,8 @@ def make_data():
 
 
 def shard(files, world, rank):
-    """contiguous file ranges balanced by window count"""
-    counts = np.array([len(f) for f in files])
-    bounds = [int(np.searchsorted(np.cumsum(counts), counts.sum() * (r + 1) / world)) + 1 for r in range(world - 1)]
-    edges = [0] + bounds + [len(files)]
+    """contiguous file ranges balanced by window count: the library's own cut (szh_shard_ranges)"""
+    edges = sz.shard_ranges([len(f) for f in files], world)
     return list(range(edges[rank], edges[rank + 1]))
 
 
@@ -58,9 +56,39 @@ def epoch(net, files, labels, idx, reduce=None):
     return local, summed
 
 
+def library_comm_main(out, rank, world, id_path):
+    """the sum through the library's communicator; its id travels through a file"""
+    import time
+    torch.cuda.set_device(0)
+    sz._capi._check(sz.lib().szh_init(0))
+    if rank == 0:
+        ident = sz.comm_unique_id()
+        with open(id_path + ".tmp", "wb") as f:
+            f.write(ident)
+        os.replace(id_path + ".tmp", id_path)
+    else:
+        for _ in range(600):
+            if os.path.exists(id_path):
+                break
+            time.sleep(0.1)
+        ident = open(id_path, "rb").read()
+    comm = sz.Comm(ident, rank, world)
+    params, files, labels = make_data()
+    net = sz.SimpleNeuralNet(*DIMS, init=params)
+    comm.broadcast_params(net, 0, 0)
+
+    def reduce(host):   # epoch() hands over a host copy; the library sums its own device vector in place
+        comm.allreduce_grad(net, torch.cuda.current_stream().cuda_stream)
+        host.copy_(grad_view(net).cpu())
+    local, summed = epoch(net, files, labels, shard(files, world, rank), reduce=reduce)
+    np.savez(os.path.join(out, f"rank{rank}.npz"), params=net.get_flat(), local=local, summed=summed)
+
+
 def main():
     out = sys.argv[1]
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    if os.environ.get("TWO_RANK_LIBRARY_COMM"):
+        return library_comm_main(out, rank, world, os.environ["TWO_RANK_LIBRARY_COMM"])
     os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
     dist.init_process_group("gloo")
     torch.cuda.set_device(0)
