@@ -44,9 +44,13 @@ __global__ __launch_bounds__(kBaseThreads, 3) void mfcc_base_kernel(const int16_
                                                                   const Segment* __restrict__ segs,
                                                                   uint32_t n_segs,
                                                                   const KernelTables* __restrict__ Tg,
-                                                                  float* __restrict__ base)
+                                                                  float* __restrict__ base,
+                                                                  const uint64_t* __restrict__ shift_p)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    // samples every unit of this launch lies further into the PCM buffer than its table says (a plan
+    // that walks along a recording; the finish kernel of the previous launch moved it on)
+    const uint64_t shift = shift_p ? *shift_p : 0;
     // the tables into LDS, once per workgroup (the only workgroup barrier of the kernel)
     const KernelTables* T = reinterpret_cast<const KernelTables*>(reinterpret_cast<const char*>(lds) + kRegionBytes);
     {
@@ -69,7 +73,7 @@ __global__ __launch_bounds__(kBaseThreads, 3) void mfcc_base_kernel(const int16_
             uint32_t wi = w0 + grp;
             const bool valid = wi < S.n_win;
             if (!valid) wi = S.n_win - 1;
-            const int16_t* win = pcm + S.pcm_off + (uint64_t)wi * kHop;
+            const int16_t* win = pcm + S.pcm_off + shift + (uint64_t)wi * kHop;
             // The tables are re-read from LDS in every iteration: letting the compiler hoist ~250
             // loop-invariant twiddle loads into registers spills.  (The opaque value is an offset,
             // not the pointer, so the address space of the loads stays known.)
@@ -139,9 +143,13 @@ __device__ __forceinline__ float quad_sum(float v)
 
 __global__ __launch_bounds__(kFinishThreads) void finish_kernel(const float* __restrict__ base,
                                                                const Segment* __restrict__ segs,
-                                                               uint32_t n_segs, float* __restrict__ out)
+                                                               uint32_t n_segs, float* __restrict__ out,
+                                                               uint64_t* __restrict__ shift_p, uint64_t advance)
 {
     __shared__ __attribute__((aligned(16))) float F[kSegWindows * kFeat];
+    // the plan moves on for its next launch (this kernel reads no PCM, and the next MFCC launch starts
+    // after this one has ended)
+    if (shift_p && blockIdx.x == 0 && threadIdx.x == 0) *shift_p += advance;
     const int f = threadIdx.x >> 2;
     const int p = threadIdx.x & 3;
     for (uint32_t sg = blockIdx.x; sg < n_segs; sg += gridDim.x) {
@@ -194,12 +202,6 @@ __global__ __launch_bounds__(kFinishThreads) void finish_kernel(const float* __r
         for (int i = threadIdx.x; i < n4; i += kFinishThreads) dst[i] = src[i];
         __syncthreads();
     }
-}
-
-__global__ void advance_kernel(Segment* segs, uint32_t n_segs, uint64_t samples)
-{
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n_segs) segs[i].pcm_off += samples;
 }
 
 }  // namespace
@@ -358,12 +360,14 @@ int plan_create_tile(Extractor* e, uint64_t pcm_off, uint32_t lead, uint32_t n_o
     return SZH_OK;
 }
 
-int plan_advance(Plan* p, uint64_t samples, hipStream_t stream)
+int plan_set_advance(Plan* p, uint64_t samples)
 {
     if (p->n_segs == 0) return SZH_OK;
-    hipLaunchKernelGGL(advance_kernel, dim3((p->n_segs + 63) / 64), dim3(64), 0, stream, p->d_segs, p->n_segs, samples);
-    SZ_HIP(hipGetLastError());
-    p->pcm_extent += samples;
+    if (!p->d_shift) {
+        SZ_HIP(hipMalloc((void**)&p->d_shift, sizeof(uint64_t)));
+        SZ_HIP(hipMemset(p->d_shift, 0, sizeof(uint64_t)));
+    }
+    p->advance = samples;
     return SZH_OK;
 }
 
@@ -372,6 +376,7 @@ void plan_destroy(Plan* p)
     if (!p) return;
     if (p->d_segs) (void)hipFree(p->d_segs);
     if (p->d_base) (void)hipFree(p->d_base);
+    if (p->d_shift) (void)hipFree(p->d_shift);
     delete p;
 }
 
@@ -388,14 +393,14 @@ int plan_run(Plan* p, const int16_t* pcm_dev, float* feats_dev, hipStream_t stre
     {
         ProfScope prof("mfcc_base", stream);
         hipLaunchKernelGGL(mfcc_base_kernel, dim3(grid_a), dim3(kBaseThreads), kBaseLdsBytes, stream, pcm_dev,
-                           p->d_segs, p->n_segs, p->ext->dev, p->d_base);
+                           p->d_segs, p->n_segs, p->ext->dev, p->d_base, p->d_shift);
     }
     SZ_HIP(hipGetLastError());
     const uint32_t grid_b = p->n_fin < 256u * 32u ? p->n_fin : 256u * 32u;
     {
         ProfScope prof("finish", stream);
         hipLaunchKernelGGL(finish_kernel, dim3(grid_b), dim3(kFinishThreads), 0, stream, p->d_base, p->d_fin,
-                           p->n_fin, feats_dev);
+                           p->n_fin, feats_dev, p->d_shift, p->advance);
     }
     SZ_HIP(hipGetLastError());
     return SZH_OK;
@@ -488,6 +493,11 @@ extern "C" int szh_extract_dev_noalloc(szh_extractor* ext, const int16_t* pcm_de
         return SZH_EINVAL;
     }
     Extractor* e = reinterpret_cast<Extractor*>(ext);
+    {   // the kernels read the extractor's tables: they must run on the device that holds them
+        int cur = -1;
+        SZ_HIP(hipGetDevice(&cur));
+        if (cur != e->device) { set_error("extractor belongs to device %d but the current device is %d", e->device, cur); return SZH_EINVAL; }
+    }
     NoAllocScratch* sc = nullptr;
     if (int rc = noalloc_scratch(&sc)) return rc;
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -498,9 +508,9 @@ extern "C" int szh_extract_dev_noalloc(szh_extractor* ext, const int16_t* pcm_de
     SZ_HIP(hipGetLastError());
     const uint32_t grid_a = (n_units + kBaseWaves - 1) / kBaseWaves;
     hipLaunchKernelGGL(mfcc_base_kernel, dim3(grid_a), dim3(kBaseThreads), kBaseLdsBytes, s, pcm_dev, sc->units, n_units,
-                       e->dev, sc->base);
+                       e->dev, sc->base, nullptr);
     SZ_HIP(hipGetLastError());
-    hipLaunchKernelGGL(finish_kernel, dim3(n_fin), dim3(kFinishThreads), 0, s, sc->base, sc->fin, n_fin, feats_dev);
+    hipLaunchKernelGGL(finish_kernel, dim3(n_fin), dim3(kFinishThreads), 0, s, sc->base, sc->fin, n_fin, feats_dev, nullptr, 0);
     SZ_HIP(hipGetLastError());
     return SZH_OK;
 }

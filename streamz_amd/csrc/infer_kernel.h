@@ -1,0 +1,365 @@
+// identify_speaker_list's loop body (lib.rs:1391-1401: forward of lib.rs:880-891, arg-max, threshold,
+// vote) for a tile of rows as ONE kernel: the feature rows are the only thing read per window and the
+// votes the only thing written; h1, h2 and the logits never leave the compute unit.
+//
+// Every layer is computed transposed, out^T = W^T . act^T, on v_mfma_f32_32x32x2_f32: the weights are
+// the A operand (a lane holds one weight row), the activations of 32 feature rows the B operand (a lane
+// holds one feature row).  A result register r of lane (m, half) then is out[row m][unit u(r)],
+// u(r) = (r & 3) + 8 (r >> 2) + 4 half -- which is exactly what the next layer's B operand wants: lane
+// (m, half) supplies act[m][k] for the k of its half of each step.  So a wave's layer-2 output feeds layer
+// 3 straight from its accumulators, and only h1, which every wave needs all of, passes through LDS.
+//
+// A workgroup of 8 waves owns MT blocks of 32 rows:
+//   1. h1^T tiles (32 units x 32 rows, K = 64: the inputs, a one for the bias, zeros) are dealt to the
+//      waves; ReLU; written to LDS as h1[row][unit] (16-byte pieces, conflict-free);
+//   2. wave w computes h2^T for units 32 w .. 32 w + 31 over all of h1: its rows of w2^T come straight
+//      from global memory (L2), 16 bytes per lane and four steps, fetched four 32-unit trips ahead, from
+//      a copy of the weights laid out in fetch order (a wave's load reads 1 KB of consecutive memory; with
+//      the matrix as it lies, every lane of a load would touch a cache line of its own); one weight
+//      fragment multiplies all MT row blocks;
+//   3. partial logits^T over the wave's 32 units of h2 (w3 as the A operand), summed over the waves
+//      through LDS; softmax over a row's classes by 16 lanes (DPP), the last maximum wins, thresholded
+//      vote into an LDS histogram; per-class probability sums in f64.
+// With MT = 1 a tile of 8192 rows is 256 workgroups, one per compute unit; each reads all weights once
+// (672 KB from L2 at 60-512-256-16), which is what 32 rows per compute unit cost; MT = 2 halves that for
+// calls with enough rows.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gemm_kernel.h"
+
+namespace sz {
+namespace infer {
+
+using gemm::f32x16;
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+constexpr int kThreads = 512, kWaves = 8;
+constexpr int kMaxClasses = 64;
+
+struct Args {
+    const float* x;    // [rows][in] feature rows, 16-byte aligned
+    uint64_t rows;
+    int in;            // a multiple of 4, <= 60
+    // The weights in the order the waves fetch them (infer_tables_kernel): every 16-byte load of a wave
+    // reads 1 KB of consecutive memory, lane (u, half) = 32 half + u taking its own four values.
+    // the three tables lie back to back at `tab`:
+    //   w1f [H1/32][8 q][64 lanes][4]: w1p[32 kt + u][32 half + 4 q + i], w1p = [w1^T | b1 | 0] ([H1][64])
+    //   w2f [H2/32][H1/32][4 q][64 lanes][4]: w2^T[32 jt + u][32 ko + 8 q + 4 half + i]
+    //   w3f [2 ct][H2/32][4 q][64 lanes][4]: w3^T[32 ct + u][32 jt + 8 q + 4 half + i], zero behind class C
+    const float* tab;
+    const float* b2;
+    const float* b3;
+    int H1, H2, C;     // H1 a multiple of 128, H2 a multiple of 32 and <= 256, C <= 64
+    float threshold;
+    unsigned long long* counts;  // [C] votes, added to (optional)
+    double* psums;               // [C] probability sums, added to (optional)
+    int tail_off;                // floats from the LDS base to the histogram
+};
+
+// floats of LDS the activations / partial logits need, and the whole dynamic allocation
+__host__ __device__ constexpr int part_ld(int nct) { return 32 * nct + 4; }
+inline size_t act_floats(int mt, int h1, int nct)
+{
+    const size_t h = (size_t)mt * 32 * (h1 + 4), p = (size_t)kWaves * mt * 32 * part_ld(nct);
+    return h > p ? h : p;
+}
+inline size_t lds_bytes(int mt, int h1, int nct) { return act_floats(mt, h1, nct) * sizeof(float) + kMaxClasses * (sizeof(unsigned int) + sizeof(double)); }
+
+inline size_t table_floats(int h1, int h2) { return (size_t)h1 * 64 + (size_t)h2 * h1 + (size_t)kMaxClasses * h2; }
+
+// the three tables, back to back at `out` (w1f, w2f, w3f); one thread per float
+__global__ __launch_bounds__(256) void infer_tables_kernel(const float* __restrict__ w1, const float* __restrict__ b1,
+                                                           const float* __restrict__ w2, const float* __restrict__ w3, int in, int H1,
+                                                           int H2, int C, float* __restrict__ out)
+{
+    const size_t n1 = (size_t)H1 * 64, n2 = (size_t)H2 * H1, n3 = (size_t)kMaxClasses * H2;
+    size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n1 + n2 + n3) return;
+    const int i = (int)(e & 3), lane = (int)((e >> 2) & 63), u = lane & 31, half = lane >> 5;
+    float v;
+    if (e < n1) {
+        const int q = (int)((e >> 8) & 7), kt = (int)(e >> 11);
+        const int unit = 32 * kt + u, k = 32 * half + 4 * q + i;
+        v = k < in ? w1[(size_t)k * H1 + unit] : (k == in ? b1[unit] : 0.0f);
+    } else if (e < n1 + n2) {
+        const size_t f = e - n1;
+        const int KT = H1 >> 5;
+        const int q = (int)((f >> 8) & 3);
+        const size_t trip = f >> 10;  // jt * KT + ko
+        const int ko = (int)(trip % KT), jt = (int)(trip / KT);
+        v = w2[(size_t)(32 * ko + 8 * q + 4 * half + i) * H2 + 32 * jt + u];
+    } else {
+        const size_t f = e - n1 - n2;
+        const int JT = H2 >> 5;
+        const int q = (int)((f >> 8) & 3);
+        const size_t blk = f >> 10;  // ct * JT + jt
+        const int jt = (int)(blk % JT), ct = (int)(blk / JT);
+        const int c = 32 * ct + u;
+        v = c < C ? w3[(size_t)(32 * jt + 8 * q + 4 * half + i) * C + c] : 0.0f;
+    }
+    out[e] = v;
+}
+
+template <int CTRL>
+__device__ __forceinline__ float dpp16(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float row16_max(float x)
+{
+    x = fmaxf(x, dpp16<0xB1>(x));
+    x = fmaxf(x, dpp16<0x4E>(x));
+    x = fmaxf(x, dpp16<0x141>(x));
+    return fmaxf(x, dpp16<0x140>(x));
+}
+__device__ __forceinline__ float row16_sum(float x)
+{
+    x += dpp16<0xB1>(x);
+    x += dpp16<0x4E>(x);
+    x += dpp16<0x141>(x);
+    return x + dpp16<0x140>(x);
+}
+
+// 16 bytes of the weight tables: a buffer load takes the tables' descriptor and a wave-uniform byte
+// offset from scalar registers, the lane's own offset as 32 bits and the piece's as an immediate, where a
+// plain load would hold a 64-bit address per load in vector registers
+typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4v load_frag(__amdgpu_buffer_rsrc_t tab, unsigned uniform_bytes, unsigned lane_bytes)
+{
+    return __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(tab, lane_bytes, uniform_bytes, 0));
+}
+
+#define SZ_MFMA32(a_, b_, c_) __builtin_amdgcn_mfma_f32_32x32x2f32((a_), (b_), (c_), 0, 0, 0)
+
+// MT: blocks of 32 rows per workgroup; NCT: blocks of 32 classes
+template <int MT, int NCT>
+__global__ __launch_bounds__(kThreads) void infer_vote_kernel(Args a)
+{
+    extern __shared__ __attribute__((aligned(16))) float ilds[];
+    const int H1 = a.H1, LD = H1 + 4;
+    constexpr int PLD = part_ld(NCT);
+    float* h1s = ilds;   // [MT * 32][LD]; later the partial logits [wave][MT][32 rows][PLD]
+    unsigned int* hist = reinterpret_cast<unsigned int*>(ilds + a.tail_off);  // [64]
+    double* dsum = reinterpret_cast<double*>(hist + kMaxClasses);             // [64] (8-byte aligned: tail_off is even)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    if (tid < kMaxClasses) { hist[tid] = 0; dsum[tid] = 0.0; }
+    const int KT = H1 >> 5, JT = a.H2 >> 5;
+    const __amdgpu_buffer_rsrc_t tab = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.tab), 0, (int)(4u * (64u * H1 + (unsigned)a.H2 * H1 + 64u * a.H2)), 0x00020000);
+    const unsigned w3_off = 4u * (64u * H1 + (unsigned)a.H2 * H1);
+    // reduction role: 16 lanes per row, lane cl takes classes cl, cl + 16, ...
+    const int rm = tid >> 4, cl = tid & 15;
+    double pacc[2 * NCT];
+#pragma unroll
+    for (int u = 0; u < 2 * NCT; ++u) pacc[u] = 0.0;
+    float b3v[2 * NCT];
+#pragma unroll
+    for (int u = 0; u < 2 * NCT; ++u) b3v[u] = cl + 16 * u < a.C ? a.b3[cl + 16 * u] : 0.0f;
+    __syncthreads();
+
+    const uint64_t n_tiles = (a.rows + 32 * MT - 1) / (32 * MT);
+    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const uint64_t row0 = tile * (32 * MT);
+        // Everything this tile reads from global memory is requested up front, so that the latencies of
+        // the rows, of the first layer's weights and of the second layer's first trips overlap.
+        f32x4v xr[MT][8];  // lane (m, half): x[m][32 half + 4 q + 0..3]
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const uint64_t r = row0 + 32 * mt + l31;
+            const float* xp = a.x + (r < a.rows ? r : a.rows - 1) * (uint64_t)a.in;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int c0 = 32 * half + 4 * q;
+                // (in is a multiple of 4: a group of four lies inside the row, or starts with the bias's one, or is padding)
+                f32x4v v = {c0 == a.in ? 1.0f : 0.0f, 0.0f, 0.0f, 0.0f};
+                if (c0 < a.in) v = *reinterpret_cast<const f32x4v*>(xp + c0);
+                xr[mt][q] = v;
+            }
+        }
+        const unsigned boff = (unsigned)lane * 16u;
+        // the wave's tiles of the first layer's weights, two in flight
+        f32x4v wa0[8], wa1[8];
+        if (wave < KT) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) wa0[q] = load_frag(tab, 8192u * wave, boff + 1024u * q);
+        }
+        if (wave + kWaves < KT) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) wa1[q] = load_frag(tab, 8192u * (wave + kWaves), boff + 1024u * q);
+        }
+        const unsigned w2_off = 256u * H1 + 4096u * (unsigned)(wave * KT);  // bytes to the wave's first trip of w2f; 4096 per trip
+        f32x4v wb[4][4];  // the second layer's weights, four trips of 32 units in flight (two of them from here on)
+        constexpr int EARLY = MT == 1 ? 2 : 0;
+        if (wave < JT) {
+#pragma unroll
+            for (int d = 0; d < EARLY; ++d)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) wb[d][q] = load_frag(tab, w2_off + 4096u * d, boff + 1024u * q);
+        }
+        // ---- 1. first layer: h1 = relu([x | 1 | 0] . w1p^T)
+        auto layer1_tile = [&](int t1, const f32x4v (&w)[8]) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc = SZ_MFMA32(w[q][i], xr[mt][q][i], acc);
+                float* dst = h1s + (size_t)(32 * mt + l31) * LD + 32 * t1 + 4 * half;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    f32x4v o;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { const float v = acc[4 * q + i]; o[i] = v > 0.0f ? v : 0.0f; }
+                    *reinterpret_cast<f32x4v*>(dst + 8 * q) = o;
+                }
+            }
+        };
+        for (int t1 = wave; t1 < KT; t1 += 2 * kWaves) {
+            layer1_tile(t1, wa0);
+            if (t1 + 2 * kWaves < KT) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) wa0[q] = load_frag(tab, 8192u * (t1 + 2 * kWaves), boff + 1024u * q);
+            }
+            if (t1 + kWaves < KT) {
+                layer1_tile(t1 + kWaves, wa1);
+                if (t1 + 3 * kWaves < KT) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) wa1[q] = load_frag(tab, 8192u * (t1 + 3 * kWaves), boff + 1024u * q);
+                }
+            }
+        }
+        if (wave < JT) {
+#pragma unroll
+            for (int d = EARLY; d < 4; ++d)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) wb[d][q] = load_frag(tab, w2_off + 4096u * d, boff + 1024u * q);
+        }
+        __syncthreads();
+        // ---- 2. second layer: the wave's 32 units of h2, over all of h1
+        f32x16 h2[MT];
+        f32x4v w3v[NCT][4];  // the output layer's weights for this wave's units
+        if (wave < JT) {
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    w3v[ct][q] = load_frag(tab, w3_off + 4096u * (unsigned)(ct * JT + wave), boff + 1024u * q);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) h2[mt][r] = 0.0f;
+            const float* hp = h1s + (size_t)l31 * LD + 4 * half;
+            for (int ko = 0; ko < KT; ko += 4) {
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    f32x4v wv[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) wv[q] = wb[d][q];
+                    if (ko + 4 + d < KT) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) wb[d][q] = load_frag(tab, w2_off + 4096u * (ko + 4 + d), boff + 1024u * q);
+                    }
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        f32x4v hv[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) hv[q] = *reinterpret_cast<const f32x4v*>(hp + (size_t)(32 * mt) * LD + 32 * (ko + d) + 8 * q);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) h2[mt] = SZ_MFMA32(wv[q][i], hv[q][i], h2[mt]);
+                    }
+                    // (keeps the compiler from moving the LDS reads of all four trips to the top, which
+                    // costs more registers than there are)
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            // bias and tanh (lib.rs:883); register 4 q + i is unit 32 wave + 8 q + 4 half + i
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4v bv = *reinterpret_cast<const f32x4v*>(a.b2 + 32 * wave + 8 * q + 4 * half);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) h2[mt][4 * q + i] = gemm::fast_tanh(h2[mt][4 * q + i] + bv[i]);
+            }
+        }
+        __syncthreads();  // h1 has been read by everyone: its space takes the partial logits
+        // ---- 3. output layer: partial logits over the wave's units, then the sum over the waves
+        if (wave < JT) {
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    f32x16 p;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) p[r] = 0.0f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) p = SZ_MFMA32(w3v[ct][r >> 2][r & 3], h2[mt][r], p);
+                    float* dst = h1s + (size_t)((wave * MT + mt) * 32 + l31) * PLD + 32 * ct + 4 * half;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        f32x4v o;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) o[i] = p[4 * q + i];
+                        *reinterpret_cast<f32x4v*>(dst + 8 * q) = o;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const uint64_t row = row0 + 32 * mt + rm;
+            const bool row_ok = row < a.rows;
+            float v[2 * NCT];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int u = 0; u < 2 * NCT; ++u) {
+                const int c = cl + 16 * u;
+                float s = b3v[u];
+                for (int w = 0; w < JT; ++w) s += h1s[(size_t)((w * MT + mt) * 32 + rm) * PLD + c];
+                v[u] = c < a.C ? s : -INFINITY;
+                mx = fmaxf(mx, v[u]);
+            }
+            mx = row16_max(mx);
+            float sum = 0.0f;
+#pragma unroll
+            for (int u = 0; u < 2 * NCT; ++u) {
+                v[u] = cl + 16 * u < a.C ? expf(v[u] - mx) : 0.0f;
+                sum += v[u];
+            }
+            sum = row16_sum(sum);
+            float best = -1.0f, best_c = -1.0f;
+#pragma unroll
+            for (int u = 0; u < 2 * NCT; ++u) {
+                const float p = v[u] / sum;
+                if (cl + 16 * u < a.C && p >= best) { best = p; best_c = (float)(cl + 16 * u); }
+                if (row_ok) pacc[u] += (double)p;
+            }
+            const float top = row16_max(best);
+            const float win = row16_max(best == top ? best_c : -1.0f);  // the last maximum wins
+            if (cl == 0 && row_ok && top >= a.threshold && win >= 0.0f) atomicAdd(&hist[(int)win], 1u);
+        }
+        __syncthreads();  // the partial logits have been read: the next tile's h1 may overwrite them
+    }
+    if (a.psums) {
+#pragma unroll
+        for (int u = 0; u < 2 * NCT; ++u)
+            if (cl + 16 * u < a.C) atomicAdd(&dsum[cl + 16 * u], pacc[u]);
+    }
+    __syncthreads();
+    if (tid < a.C) {
+        if (a.counts && hist[tid]) atomicAdd(&a.counts[tid], (unsigned long long)hist[tid]);
+        if (a.psums) atomicAdd(&a.psums[tid], dsum[tid]);
+    }
+}
+
+}  // namespace infer
+}  // namespace sz

@@ -52,6 +52,10 @@ struct Plan {
     uint32_t n_fin = 0;
     Segment* d_fin = nullptr;       // windows that are finished and written (== d_segs unless a tile)
     float* d_base = nullptr;        // [base windows][20] un-normalised MFCCs
+    // a plan that walks along a recording: samples added to every unit's position (device word, moved on
+    // by `advance` at the end of every run), see plan_set_advance
+    uint64_t* d_shift = nullptr;
+    uint64_t advance = 0;
 };
 
 int extractor_create(Extractor** out);
@@ -64,8 +68,9 @@ int plan_run(Plan* p, const int16_t* pcm_dev, float* feats_dev, hipStream_t stre
 // feats rows 0 .. n_out - 1.  lead / trail are the neighbours the deltas need (2, or 0 at the
 // recording's own ends, where add_deltas replicates the edge, lib.rs:215-220).
 int plan_create_tile(Extractor* e, uint64_t pcm_off, uint32_t lead, uint32_t n_out, uint32_t trail, Plan** out);
-// moves every window of the plan `samples` further into the PCM buffer (stream-ordered)
-int plan_advance(Plan* p, uint64_t samples, hipStream_t stream);
+// from now on every plan_run leaves the plan `samples` further into the PCM buffer for the next one (the
+// move is part of the run's last kernel: no extra launch, and a captured run replays it)
+int plan_set_advance(Plan* p, uint64_t samples);
 // augment (lib.rs:103-116) of n device-resident samples; noise_dev NULL -> counter-based draws
 // keyed by (seed, counter0 + i).
 // looks up the current device's copy of the fixed array szh_extract_dev_noalloc works in
@@ -90,6 +95,7 @@ struct Workspace {
     uint32_t* w3s = nullptr;      // the same for w3^T and w3 (GEMM output path only)
     float* w3t = nullptr;         // w3 transposed, the source of its planes
     float* w1t = nullptr;         // [hidden1][ldx]: w1 transposed, zeros behind its `in` columns
+    float* vote_tab = nullptr;    // the three layers' weights in the fetch order of the fused vote kernel (infer_kernel.h)
     double* stat_slab = nullptr;  // per-workgroup {loss, live rows} partials of the head kernels
     uint64_t slab_floats = 0;
     // regions of `slab` (float offsets): split-K partials of dW1|db1, dW2, dW3|db3 and db2
@@ -175,8 +181,11 @@ int net_read_totals(Net* n, hipStream_t s, double* loss_sum, double* live_rows);
 // per-window votes (counts_dev[out], optional) and per-class probability sums (psums_dev[out],
 // optional; the sums identify_speaker compares, lib.rs:1290-1297) of `rows` feature rows, added
 // to what the arrays hold
+// tables_prepared: net_vote_prepare ran on this net since its parameters last changed (callers that vote
+// on many batches in a row, the tiled identify, prepare once)
 int net_vote_dev(Net* n, const float* x_dev, uint64_t rows, float threshold, unsigned long long* counts_dev,
-                 double* psums_dev, hipStream_t s);
+                 double* psums_dev, hipStream_t s, bool tables_prepared = false);
+int net_vote_prepare(Net* n, hipStream_t s);
 // Pooled embedding (un-normalised) of device feature rows, written to host memory out[hidden2]:
 // mode 0 mean of forward_embedding, 1 median of forward_embedding, 2 median of embed.
 int net_pool_host(Net* n, const float* x_dev, uint64_t rows, int mode, float* out);

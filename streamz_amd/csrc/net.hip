@@ -14,6 +14,7 @@
 
 #include "gemm_bf16x3.h"
 #include "gemm_kernel.h"
+#include "infer_kernel.h"
 #include "internal.h"
 #include "prof.h"
 #include "rng.h"
@@ -1384,6 +1385,7 @@ int ensure_workspace(Net* n, uint64_t rows)
     if (w.w3s) { (void)hipFree(w.w3s); w.w3s = nullptr; }
     if (w.w3t) { (void)hipFree(w.w3t); w.w3t = nullptr; }
     if (w.w1t) { (void)hipFree(w.w1t); w.w1t = nullptr; }
+    if (w.vote_tab) { (void)hipFree(w.vote_tab); w.vote_tab = nullptr; }
     if (w.live) { (void)hipFree(w.live); w.live = nullptr; }
     if (w.mask) { (void)hipFree(w.mask); w.mask = nullptr; }
     if (w.stat_slab) { (void)hipFree(w.stat_slab); w.stat_slab = nullptr; }
@@ -1417,6 +1419,7 @@ int ensure_workspace(Net* n, uint64_t rows)
     SZ_HIP(hipMalloc((void**)&w.w3s, 2 * 3 * ((uint64_t)n->h2 * n->out + 2) * sizeof(uint16_t)));
     SZ_HIP(hipMalloc((void**)&w.w3t, ((uint64_t)n->h2 * n->out + 1) * sizeof(float)));
     SZ_HIP(hipMalloc((void**)&w.w1t, (uint64_t)n->h1 * w.ldx * sizeof(float)));
+    SZ_HIP(hipMalloc((void**)&w.vote_tab, infer::table_floats((int)n->h1, (int)n->h2) * sizeof(float)));
     SZ_HIP(hipMalloc((void**)&w.stat_slab, 2 * head_blocks * sizeof(double)));
     SZ_HIP(hipMalloc((void**)&w.w2t, ((uint64_t)n->h1 * n->h2 + 8 * 64 * 4 * ((n->h2 + 15) / 16)) * sizeof(float)));
     w.rows = R;
@@ -1633,6 +1636,8 @@ void net_destroy(Net* n)
     if (w.w2s) (void)hipFree(w.w2s);
     if (w.w3s) (void)hipFree(w.w3s);
     if (w.w3t) (void)hipFree(w.w3t);
+    if (w.w1t) (void)hipFree(w.w1t);
+    if (w.vote_tab) (void)hipFree(w.vote_tab);
     if (w.live) (void)hipFree(w.live);
     if (w.mask) (void)hipFree(w.mask);
     if (w.stat_slab) (void)hipFree(w.stat_slab);
@@ -2148,10 +2153,69 @@ int net_stage_pinned(Net* n, size_t bytes, void** out)
     return SZH_OK;
 }
 
+// ---- the vote of a batch of feature rows as one kernel (infer_kernel.h) -------------------------
+static bool infer_fused_applies(const Net* n)
+{
+    static const bool off = std::getenv("STREAMZ_NO_FUSED_VOTE") != nullptr;  // (the per-layer path, for comparisons)
+    return !off && n->in <= 60 && n->in % 4 == 0 && n->h1 % 128 == 0 && n->h1 <= 1024 && n->h2 % 32 == 0 && n->h2 <= 256 && n->out >= 1 &&
+           n->out <= (uint32_t)infer::kMaxClasses;
+}
+
+// the weights in that kernel's fetch order (the workspace must exist)
+int net_vote_prepare(Net* n, hipStream_t s)
+{
+    if (!infer_fused_applies(n)) return SZH_OK;
+    if (int rc = ensure_workspace(n, 256)) return rc;
+    const float* P = n->d_params;
+    ProfScope prof("w2t", s);
+    const size_t total = infer::table_floats((int)n->h1, (int)n->h2);
+    hipLaunchKernelGGL(infer::infer_tables_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, P + n->off_w1(),
+                       P + n->off_b1(), P + n->off_w2(), P + n->off_w3(), (int)n->in, (int)n->h1, (int)n->h2, (int)n->out, n->ws.vote_tab);
+    SZ_HIP(hipGetLastError());
+    return SZH_OK;
+}
+
+template <int MT, int NCT>
+static int launch_infer_vote_one(const infer::Args& a0, size_t lds, hipStream_t s)
+{
+    infer::Args a = a0;
+    if (int rc = allow_dynamic_lds((const void*)infer::infer_vote_kernel<MT, NCT>, lds)) return rc;
+    const uint64_t tiles = (a.rows + 32 * MT - 1) / (32 * MT);
+    const unsigned blocks = (unsigned)std::min<uint64_t>(tiles, (uint64_t)compute_units());
+    ProfScope prof("vote_fused", s);
+    hipLaunchKernelGGL((infer::infer_vote_kernel<MT, NCT>), dim3(blocks), dim3(infer::kThreads), lds, s, a);
+    SZ_HIP(hipGetLastError());
+    return SZH_OK;
+}
+
+static int launch_infer_vote(Net* n, const float* x_dev, uint64_t rows, float threshold, unsigned long long* counts_dev,
+                             double* psums_dev, hipStream_t s)
+{
+    const float* P = n->d_params;
+    infer::Args a{};
+    a.x = x_dev; a.rows = rows; a.in = (int)n->in;
+    a.tab = n->ws.vote_tab; a.b2 = P + n->off_b2(); a.b3 = P + n->off_b3();
+    a.H1 = (int)n->h1; a.H2 = (int)n->h2; a.C = (int)n->out;
+    a.threshold = threshold; a.counts = counts_dev; a.psums = psums_dev;
+    const int nct = n->out <= 32 ? 1 : 2;
+    // two blocks of 32 rows per workgroup (every weight fragment used twice) once that still leaves
+    // every compute unit two tiles
+    const int mt = (rows >= 128ull * compute_units() && infer::lds_bytes(2, a.H1, nct) <= 150 * 1024) ? 2 : 1;
+    a.tail_off = (int)infer::act_floats(mt, a.H1, nct);
+    const size_t lds = infer::lds_bytes(mt, a.H1, nct);
+    if (mt == 2) return nct == 1 ? launch_infer_vote_one<2, 1>(a, lds, s) : launch_infer_vote_one<2, 2>(a, lds, s);
+    return nct == 1 ? launch_infer_vote_one<1, 1>(a, lds, s) : launch_infer_vote_one<1, 2>(a, lds, s);
+}
+
 int net_vote_dev(Net* n, const float* x_dev, uint64_t rows, float threshold, unsigned long long* counts_dev,
-                 double* psums_dev, hipStream_t s)
+                 double* psums_dev, hipStream_t s, bool tables_prepared)
 {
     if (rows == 0 || n->out == 0) return SZH_OK;
+    if (infer_fused_applies(n) && ((uintptr_t)x_dev & 15) == 0) {
+        if (!tables_prepared)
+            if (int rc = net_vote_prepare(n, s)) return rc;
+        return launch_infer_vote(n, x_dev, rows, threshold, counts_dev, psums_dev, s);
+    }
     const uint64_t base = n->ws.row_base;
     if (base != 0 && (rows > chunk_rows(n) || base + rows > n->ws.rows)) { set_error("vote: rows beyond the reserved workspace"); return SZH_EINVAL; }
     int rc = ensure_workspace(n, base + rows);

@@ -2,7 +2,8 @@
 // batch: the windows are processed in tiles of a fixed number of windows.  Every tile runs
 // the same launch sequence (MFCCs of the tile plus two neighbour windows each side, deltas
 // and z-score, three layers, softmax, vote), so the sequence is captured once into a HIP
-// graph and replayed; the votes accumulate in device memory and are read once at the end.
+// graph and replayed (the plan's move to the next tile is part of its last extraction kernel); the
+// votes accumulate in device memory and are read once at the end.
 //
 // The deltas of a window need the MFCCs of windows t-2 .. t+2 (add_deltas applied twice,
 // lib.rs:321-322), so a tile recomputes the MFCCs of two windows of each neighbour tile
@@ -79,16 +80,14 @@ int run_tile(Net* n, Plan* plan, const int16_t* pcm_dev, float* feat, uint64_t r
 {
     int rc = plan_run(plan, pcm_dev, feat, s);
     if (rc) return rc;
-    return net_vote_dev(n, feat, rows, t.threshold, t.counts_dev, t.psums_dev, s);
+    return net_vote_dev(n, feat, rows, t.threshold, t.counts_dev, t.psums_dev, s, true);
 }
 
-// Captures run_tile (plus `advance` samples of plan movement) on stream s.
-int capture_tile(Resources& r, int slot, Net* n, const int16_t* pcm_dev, uint32_t rows, const Tally& tally,
-                 uint64_t advance)
+// Captures run_tile on stream s.
+int capture_tile(Resources& r, int slot, Net* n, const int16_t* pcm_dev, uint32_t rows, const Tally& tally)
 {
     SZ_HIP(hipStreamBeginCapture(r.compute, hipStreamCaptureModeRelaxed));
     int rc = run_tile(n, r.mid, pcm_dev, static_cast<float*>(r.feat), rows, tally, r.compute);
-    if (rc == SZH_OK && advance) rc = plan_advance(r.mid, advance, r.compute);
     const hipError_t he = hipStreamEndCapture(r.compute, &r.graph[slot]);
     if (rc) return rc;
     if (he != hipSuccess) return hip_fail(he, "hipStreamEndCapture");
@@ -133,6 +132,9 @@ int identify_tiled(Net* n, Extractor* e, const int16_t* pcm, bool pcm_on_device,
     }
     SZ_HIP(hipMalloc(&r.feat, feat_rows * kFeat * sizeof(float)));
     float* feat = static_cast<float*>(r.feat);
+    // the weight images the vote kernel reads, once for all tiles (the lanes start after r.compute has drained)
+    rc = net_vote_prepare(n, r.compute);
+    if (rc) return rc;
 
     if (pcm_on_device) {
         if (single) {
@@ -150,11 +152,9 @@ int identify_tiled(Net* n, Extractor* e, const int16_t* pcm, bool pcm_on_device,
         if (n_mid && prof_enabled()) {
             // event pairs inside a captured sequence would be replayed, not re-recorded
             rc = plan_create_tile(e, (B - 2) * kHop, 2, (uint32_t)B, 2, &r.mid);
+            if (rc == SZH_OK) rc = plan_set_advance(r.mid, B * kHop);
             if (rc) return rc;
-            for (uint64_t t = 0; t < n_mid && rc == SZH_OK; ++t) {
-                rc = run_tile(n, r.mid, pcm, feat, B, tally, r.compute);
-                if (rc == SZH_OK) rc = plan_advance(r.mid, B * kHop, r.compute);
-            }
+            for (uint64_t t = 0; t < n_mid && rc == SZH_OK; ++t) rc = run_tile(n, r.mid, pcm, feat, B, tally, r.compute);
             if (rc) return rc;
         } else if (n_mid) {
             // Lane l takes interior tiles l, l + lanes, ...: its plan starts at tile l and moves on by
@@ -164,11 +164,11 @@ int identify_tiled(Net* n, Extractor* e, const int16_t* pcm, bool pcm_on_device,
             for (int l = 0; l < lanes; ++l) {
                 SZ_HIP(hipStreamCreateWithFlags(&r.lane_stream[l], hipStreamNonBlocking));
                 rc = plan_create_tile(e, (B - 2 + (uint64_t)l * B) * kHop, 2, (uint32_t)B, 2, &r.lane_plan[l]);
+                if (rc == SZH_OK) rc = plan_set_advance(r.lane_plan[l], (uint64_t)lanes * B * kHop);
                 if (rc) return rc;
                 n->ws.row_base = (uint64_t)l * B;
                 SZ_HIP(hipStreamBeginCapture(r.lane_stream[l], hipStreamCaptureModeRelaxed));
                 rc = run_tile(n, r.lane_plan[l], pcm, feat + (uint64_t)l * B * kFeat, B, tally, r.lane_stream[l]);
-                if (rc == SZH_OK) rc = plan_advance(r.lane_plan[l], (uint64_t)lanes * B * kHop, r.lane_stream[l]);
                 const hipError_t he = hipStreamEndCapture(r.lane_stream[l], &r.lane_graph[l]);
                 n->ws.row_base = 0;
                 if (rc) return rc;
@@ -234,7 +234,7 @@ int identify_tiled(Net* n, Extractor* e, const int16_t* pcm, bool pcm_on_device,
             if (rc) return rc;
         } else {
             if (!r.exec[slot]) {
-                rc = capture_tile(r, slot, n, buf, (uint32_t)B, tally, 0);
+                rc = capture_tile(r, slot, n, buf, (uint32_t)B, tally);
                 if (rc) return rc;
             }
             SZ_HIP(hipGraphLaunch(r.exec[slot], r.compute));
