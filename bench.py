@@ -176,7 +176,17 @@ def other_figures(sz, ext, plan, pcm, feats, net_dims, n_win, dev, lr, dropout):
         dt = time.perf_counter() - t0
         t_stream = dt if t_stream is None else min(t_stream, dt)
     del rec
+    # flops of one window's forward pass (lib.rs:880-891): the three layers' multiply-adds
+    fwd_flops = 2 * (net_dims[0] * net_dims[1] + net_dims[1] * net_dims[2] + net_dims[2] * net_dims[3])
+
+    def mfma_roofline(windows_per_s, what):
+        ach = fwd_flops * windows_per_s / 1e12
+        return {"bound": "mfma", "achieved": ach, "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MATRIX_TFLOPS,
+                "flops_per_window": fwd_flops, "note": what}
     return {"identify_100h_windows_per_s": sz.window_count(n_stream) / t_stream,
+            "identify_100h_roofline": mfma_roofline(sz.window_count(n_stream) / t_stream,
+                                                    "whole call (extraction of every tile included) against the f32 matrix peak"),
+            "infer_roofline": mfma_roofline(n_win / t_inf, "extract + vote over all clips against the f32 matrix peak"),
             "identify_100h_seconds": t_stream,
             "identify_100h_note": "configs[3]: identify_speaker_list over 100 h of PCM resident in HBM, tiles of 8192 "
                                   "windows, one HIP graph replay per tile, votes read once at the end",

@@ -251,11 +251,11 @@ int pretrain_epochs_dev(Net* n, const float* d_win, uint64_t n_win, const float*
             if (have_keep)
                 SZ_HIP(hipMemcpy(d_keeps.p, rng->keep + (size_t)(ep_first + e0) * n_win * kFeat, (size_t)ne * n_win * kFeat,
                                  hipMemcpyHostToDevice));
-            // the dropout stream is keyed by (seed of the group, position in the group, feature)
+            // the dropout stream is keyed by (seed, absolute epoch * n_win + position, feature) on either path
             rc = net_pretrain_steps(n, d_win, (uint32_t)n_win, d_perms.as<uint32_t>(),
-                                    have_keep ? d_keeps.as<uint8_t>() : nullptr, dropout, mix64(seed + ep_first + e0), d_tgt,
+                                    have_keep ? d_keeps.as<uint8_t>() : nullptr, dropout, seed, (uint64_t)(ep_first + e0) * n_win, d_tgt,
                                     ne, (uint32_t)bs, lr, nullptr);
-            if (rc == SZH_STEP_NOT_RUN) {  // parameters untouched: the same epochs, same shuffles, layer by layer
+            if (rc == SZH_STEP_NOT_RUN) {  // parameters untouched: the same epochs, same shuffles, same dropout draws, layer by layer
                 for (uint32_t e = 0; e < ne; ++e) {
                     rc = epoch_per_layer(ep_first + e0 + e, orders.data() + (size_t)e * n_win);
                     if (rc) return rc;

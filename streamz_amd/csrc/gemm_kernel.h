@@ -61,11 +61,13 @@ struct GemmArgs {
 
 struct Frag4 { float v[4]; };
 
-// tanh from the hardware exponential; absolute error ~1e-7
+// tanh from the hardware exponential; absolute error ~1e-7; a NaN stays a NaN (the clamp alone would
+// turn it into -1, where the reference's tanh, lib.rs:883, carries it on)
 __device__ __forceinline__ float fast_tanh(float x)
 {
     const float t = __expf(2.0f * fminf(fmaxf(x, -15.0f), 15.0f));
-    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(t + 1.0f);  // v_rcp_f32: 1 ulp
+    const float y = 1.0f - 2.0f * __builtin_amdgcn_rcpf(t + 1.0f);  // v_rcp_f32: 1 ulp
+    return x != x ? x : y;
 }
 
 __device__ __forceinline__ Frag4 load4(const float* base, int64_t row, int col, int ld, int row_max, int col_max,
@@ -244,7 +246,7 @@ __device__ __forceinline__ void finish_values(const GemmArgs& g, f32x16 (&acc)[2
                 else if (EPI == EPI_BIAS) v += bias;
                 else if (EPI == EPI_MUL_DTANH) { const float h = g.aux[(size_t)row * g.ldaux + col]; v *= (1.0f - h * h); }
                 else if (EPI == EPI_MUL_DRELU) { const float h = g.aux[(size_t)row * g.ldaux + col]; v *= (h > 0.0f ? 1.0f : 0.0f); }
-                else if (EPI == EPI_MUL_MASK) { if (!((mword >> (rofs + 4 * half)) & 1u)) v = 0.0f; }
+                else if (EPI == EPI_MUL_MASK) v *= ((mword >> (rofs + 4 * half)) & 1u) ? 1.0f : 0.0f;  // a product, as lib.rs:1039-1040: 0 x NaN stays NaN
                 acc[tm][tn][r] = v;
             }
         }

@@ -174,9 +174,12 @@ bool step_kernel_applies(const Net* n, uint32_t batch_size, uint64_t n_steps);
 // -- its workgroups would not all be resident, or one of them gave up waiting for the others --
 // and the parameters are exactly as before the call: the caller takes the per-layer path.
 constexpr int SZH_STEP_NOT_RUN = 1;
+// Dropout draws are keyed by (seed, key_row0 + epoch * n_win + position, feature) with `epoch` counted
+// from the launch's first one: the caller passes the rows of the epochs before it, so that the draws
+// equal those of net_accumulate with row_counter0 = that position.
 int net_pretrain_steps(Net* n, const float* d_win, uint32_t n_win, const uint32_t* d_perm, const uint8_t* d_keep,
-                       float dropout, uint64_t seed, const float* d_target, uint32_t epochs, uint32_t batch_size,
-                       float lr, hipStream_t s);
+                       float dropout, uint64_t seed, uint64_t key_row0, const float* d_target, uint32_t epochs,
+                       uint32_t batch_size, float lr, hipStream_t s);
 int net_read_totals(Net* n, hipStream_t s, double* loss_sum, double* live_rows);
 // per-window votes (counts_dev[out], optional) and per-class probability sums (psums_dev[out],
 // optional; the sums identify_speaker compares, lib.rs:1290-1297) of `rows` feature rows, added

@@ -67,6 +67,7 @@ struct StepArgs {
     const uint8_t* keep;     // [epochs][n_win][60] explicit dropout masks, or null
     float dropout;
     uint64_t seed;
+    uint64_t key_row0;       // dropout draws are keyed by (seed, key_row0 + position in perm, feature): the rows before this launch's first epoch
     const float* target;     // [out]
     uint32_t epochs, bs;
     float lr;
@@ -96,11 +97,13 @@ __device__ __forceinline__ float dpp16(float v)
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
 }
 
-// tanh from the hardware exponential and reciprocal; absolute error ~1e-7
+// tanh from the hardware exponential and reciprocal; absolute error ~1e-7; a NaN stays a NaN (the clamp
+// alone would turn it into -1, where the reference's tanh, lib.rs:883, carries it on)
 __device__ __forceinline__ float step_tanh(float x)
 {
     const float t = __expf(2.0f * fminf(fmaxf(x, -15.0f), 15.0f));
-    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(t + 1.0f);
+    const float y = 1.0f - 2.0f * __builtin_amdgcn_rcpf(t + 1.0f);
+    return x != x ? x : y;
 }
 
 // LDS layout, shared by the kernel and the host-side size computation (floats, every piece on a
@@ -240,7 +243,7 @@ __global__ __launch_bounds__(kStepThreads) void step_kernel(StepArgs a)
                 v = a.win[(size_t)idx[q] * IN + ej[q]];
                 bool drop = false;
                 if (a.keep) drop = a.keep[at * IN + ej[q]] == 0;
-                else if (a.dropout > 0.0f) drop = uniform01(a.seed, at, (uint64_t)ej[q]) < a.dropout;
+                else if (a.dropout > 0.0f) drop = uniform01(a.seed, a.key_row0 + at, (uint64_t)ej[q]) < a.dropout;
                 if (drop) v = 0.0f;
             }
             xv[q] = v;
@@ -404,6 +407,21 @@ __global__ __launch_bounds__(kStepThreads) void step_kernel(StepArgs a)
                 // element count the workgroups that have added to it (at most 32 addends below 2^52 never
                 // carry into them), so an element says itself when it is complete and no flag is needed.
                 unsigned long long* accb = a.acc + (size_t)acc_cur * H2 * kStepRows;
+                // A partial that the fixed-point format cannot hold (2^19 or more in magnitude, infinite, NaN)
+                // must not be clamped silently: the reference's arithmetic carries such values on
+                // (lib.rs:1016-1059).  The workgroup reports it (abort word 2) and the host repeats the call
+                // with the exchange in f32.
+                bool unfit = false;
+#pragma unroll
+                for (int u = 0; u < TPWMAX; ++u)
+                    if (g4 < 2 && u < ntw) {
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) unfit = unfit || !(fabsf(acc[u][v]) < kFixClamp);
+                    }
+                if (__builtin_amdgcn_ballot_w64(unfit) != 0 && lane == 0) {
+                    __hip_atomic_store(a.abort_flag, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ctl[16] = 0;   // looked at after the next workgroup barrier
+                }
 #pragma unroll
                 for (int u = 0; u < TPWMAX; ++u)
                     if (g4 < 2 && u < ntw) {
@@ -469,8 +487,9 @@ __global__ __launch_bounds__(kStepThreads) void step_kernel(StepArgs a)
             auto gave_up = [&](unsigned long long since) -> bool {
                 const unsigned long long waited = wall_clock64() - since;
                 if (waited < 2000ull) return false;   // the abort word is looked at after 20 us of waiting
-                if (waited > kStepTimeoutTicks || __hip_atomic_load(a.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                    __hip_atomic_store(a.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int seen = __hip_atomic_load(a.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (waited > kStepTimeoutTicks || seen) {
+                    if (!seen) __hip_atomic_store(a.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (a reported reason stays)
                     ctl[16] = 0;   // looked at after the next workgroup barrier
                     return true;
                 }
@@ -760,7 +779,7 @@ __global__ __launch_bounds__(kStepThreads) void step_kernel(StepArgs a)
 #pragma unroll
                     for (int st = 0; st < kStepRows / 4; ++st) {
                         const float sum = (p[ib][st][0] + p[ib][st][1]) + (p[ib][st][2] + p[ib][st][3]);
-                        bf[ib][st] = hm[ib][st] > 0.0f ? sum : 0.0f;
+                        bf[ib][st] = sum * (hm[ib][st] > 0.0f ? 1.0f : 0.0f);  // a product, as lib.rs:1039-1040: 0 x NaN stays NaN
                     }
                 f32x4 acc[2];
 #pragma unroll
@@ -843,8 +862,8 @@ bool step_kernel_applies(const Net* n, uint32_t batch_size, uint64_t n_steps)
 }
 
 int net_pretrain_steps(Net* n, const float* d_win, uint32_t n_win, const uint32_t* d_perm, const uint8_t* d_keep,
-                       float dropout, uint64_t seed, const float* d_target, uint32_t epochs, uint32_t batch_size,
-                       float lr, hipStream_t s)
+                       float dropout, uint64_t seed, uint64_t key_row0, const float* d_target, uint32_t epochs,
+                       uint32_t batch_size, float lr, hipStream_t s)
 {
     // STREAMZ_STEP_FORCE_ABORT (test hook): 1 = a workgroup reports a time-out, the caller falls back;
     // 2 = the same, reported as an error instead
@@ -873,7 +892,7 @@ int net_pretrain_steps(Net* n, const float* d_win, uint32_t n_win, const uint32_
     a.params = n->d_params;
     a.params_out = reinterpret_cast<float*>(base + part_bytes);
     a.h1 = (int)n->h1; a.h2 = (int)n->h2; a.out = (int)n->out;
-    a.win = d_win; a.n_win = n_win; a.perm = d_perm; a.keep = d_keep; a.dropout = dropout; a.seed = seed;
+    a.win = d_win; a.n_win = n_win; a.perm = d_perm; a.keep = d_keep; a.dropout = dropout; a.seed = seed; a.key_row0 = key_row0;
     a.target = d_target; a.epochs = epochs; a.bs = batch_size; a.lr = lr;
     a.part = reinterpret_cast<float*>(base);
     a.flags = reinterpret_cast<unsigned*>(base + part_bytes + shadow_bytes);
@@ -920,7 +939,9 @@ int net_pretrain_steps(Net* n, const float* d_win, uint32_t n_win, const uint32_
             std::fprintf(stderr, "\n");
         }
         if (!ran && a.force_abort) break;   // the test hook asks for the failure itself
-        if (!ran && onex) one_xcd_failed.store(true);
+        // abort word 2: a partial sum did not fit the one-XCD exchange's fixed-point format; the launch over
+        // the chip, whose exchange is f32, takes this call (and says nothing about later calls)
+        if (!ran && onex && tail.abort != 2) one_xcd_failed.store(true);
     }
     if (d_prof && ran) {
         unsigned long long h[kStepProfSlots] = {};
