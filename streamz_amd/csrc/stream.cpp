@@ -22,6 +22,13 @@ namespace sz {
 namespace {
 
 constexpr int kMaxLanes = 4;   // tiles of device-resident PCM kept in flight at once
+// Replays queued per lane before the host waits for the oldest of them.  The queue only has to cover
+// the host's launch jitter (a replay is tens of microseconds of GPU work, so 16 of them are about a
+// millisecond); it is kept short on purpose: with the whole recording queued at once (4 843 replays for
+// 100 h) processes that STARTED on the same GPU meanwhile crashed in their first kernel launch on this
+// image -- seen in an earlier round, cause not established, so nothing here relies on a "safe" depth
+// having been measured.
+constexpr int kReplayDepth = 16;
 
 struct Resources {
     hipStream_t compute = nullptr, copy = nullptr;
@@ -29,6 +36,7 @@ struct Resources {
     // feature rows, range of workspace rows and captured graph, so that a tile too small to fill the
     // chip overlaps with its neighbours
     hipStream_t lane_stream[kMaxLanes] = {};
+    hipEvent_t lane_done[kMaxLanes][kReplayDepth] = {};   // ring of "replay finished" events per lane
     Plan* lane_plan[kMaxLanes] = {};
     hipGraph_t lane_graph[kMaxLanes] = {};
     hipGraphExec_t lane_exec[kMaxLanes] = {};
@@ -45,6 +53,8 @@ struct Resources {
         if (copy) (void)hipStreamSynchronize(copy);
         for (int i = 0; i < kMaxLanes; ++i) {
             if (lane_stream[i]) (void)hipStreamSynchronize(lane_stream[i]);
+            for (int k = 0; k < kReplayDepth; ++k)
+                if (lane_done[i][k]) (void)hipEventDestroy(lane_done[i][k]);
             if (lane_exec[i]) (void)hipGraphExecDestroy(lane_exec[i]);
             if (lane_graph[i]) (void)hipGraphDestroy(lane_graph[i]);
             plan_destroy(lane_plan[i]);
@@ -154,7 +164,10 @@ int identify_tiled(Net* n, Extractor* e, const int16_t* pcm, bool pcm_on_device,
             rc = plan_create_tile(e, (B - 2) * kHop, 2, (uint32_t)B, 2, &r.mid);
             if (rc == SZH_OK) rc = plan_set_advance(r.mid, B * kHop);
             if (rc) return rc;
-            for (uint64_t t = 0; t < n_mid && rc == SZH_OK; ++t) rc = run_tile(n, r.mid, pcm, feat, B, tally, r.compute);
+            for (uint64_t t = 0; t < n_mid && rc == SZH_OK; ++t) {
+                rc = run_tile(n, r.mid, pcm, feat, B, tally, r.compute);
+                if ((t & 63) == 63) SZ_HIP(hipStreamSynchronize(r.compute));   // a short queue here too
+            }
             if (rc) return rc;
         } else if (n_mid) {
             // Lane l takes interior tiles l, l + lanes, ...: its plan starts at tile l and moves on by
@@ -174,17 +187,17 @@ int identify_tiled(Net* n, Extractor* e, const int16_t* pcm, bool pcm_on_device,
                 if (rc) return rc;
                 if (he != hipSuccess) return hip_fail(he, "hipStreamEndCapture");
                 SZ_HIP(hipGraphInstantiate(&r.lane_exec[l], r.lane_graph[l], nullptr, nullptr, 0));
+                for (int k = 0; k < kReplayDepth; ++k) SZ_HIP(hipEventCreateWithFlags(&r.lane_done[l][k], hipEventDisableTiming));
             }
             // the first tile (direct launches on r.compute) used the rows of lane 0
             SZ_HIP(hipStreamSynchronize(r.compute));
             for (uint64_t t = 0; t < n_mid; ++t) {
-                SZ_HIP(hipGraphLaunch(r.lane_exec[t % lanes], r.lane_stream[t % lanes]));
-                // Bound the replays in flight.  Thousands of queued replays (4 843 for 100 h) exhaust
-                // driver-side state that other processes need: while they were queued, and for as
-                // long as this process lived afterwards, any newly started process on the GPU
-                // crashed in its first kernel launch.
-                if ((t & 255) == 255)
-                    for (int l = 0; l < lanes; ++l) SZ_HIP(hipStreamSynchronize(r.lane_stream[l]));
+                const int l = (int)(t % lanes);
+                const int slot = (int)((t / lanes) % kReplayDepth);
+                // at most kReplayDepth replays queued per lane: wait for the one that used this slot
+                if (t / lanes >= (uint64_t)kReplayDepth) SZ_HIP(hipEventSynchronize(r.lane_done[l][slot]));
+                SZ_HIP(hipGraphLaunch(r.lane_exec[l], r.lane_stream[l]));
+                SZ_HIP(hipEventRecord(r.lane_done[l][slot], r.lane_stream[l]));
             }
             for (int l = 0; l < lanes; ++l) SZ_HIP(hipStreamSynchronize(r.lane_stream[l]));
         }
@@ -224,7 +237,10 @@ int identify_tiled(Net* n, Extractor* e, const int16_t* pcm, bool pcm_on_device,
         const uint64_t s0 = (out_first - lead) * kHop;
         const uint64_t len = span(lead + rows + trail);
         int16_t* buf = static_cast<int16_t*>(r.pcm[slot]);
-        if (j >= 2) SZ_HIP(hipStreamWaitEvent(r.copy, r.done[slot], 0));
+        if (j >= 2) {
+            SZ_HIP(hipEventSynchronize(r.done[slot]));   // the host stays at most two tiles ahead of the GPU
+            SZ_HIP(hipStreamWaitEvent(r.copy, r.done[slot], 0));
+        }
         SZ_HIP(hipMemcpyAsync(buf, pcm + s0, len * sizeof(int16_t), hipMemcpyHostToDevice, r.copy));
         SZ_HIP(hipEventRecord(r.ready[slot], r.copy));
         SZ_HIP(hipStreamWaitEvent(r.compute, r.ready[slot], 0));
@@ -240,7 +256,6 @@ int identify_tiled(Net* n, Extractor* e, const int16_t* pcm, bool pcm_on_device,
             SZ_HIP(hipGraphLaunch(r.exec[slot], r.compute));
         }
         SZ_HIP(hipEventRecord(r.done[slot], r.compute));
-        if ((j & 255) == 255) SZ_HIP(hipStreamSynchronize(r.compute));  // bounded queue depth, as above
     }
     SZ_HIP(hipStreamSynchronize(r.compute));
     return SZH_OK;
