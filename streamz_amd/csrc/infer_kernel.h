@@ -132,6 +132,11 @@ __device__ __forceinline__ f32x4v load_frag(__amdgpu_buffer_rsrc_t tab, unsigned
 }
 
 #define SZ_MFMA32(a_, b_, c_) __builtin_amdgcn_mfma_f32_32x32x2f32((a_), (b_), (c_), 0, 0, 0)
+// tools/infer_bench.hip builds timing-only variants with parts of a tile left out (bit 1: the first
+// layer's matrix instructions, 2: the second layer's, 4: output layer, softmax and vote, 8: the final global atomics)
+#ifndef SZ_INFER_ABLATE
+#define SZ_INFER_ABLATE 0
+#endif
 
 // MT: blocks of 32 rows per workgroup; NCT: blocks of 32 classes
 template <int MT, int NCT>
@@ -209,7 +214,10 @@ __global__ __launch_bounds__(kThreads) void infer_vote_kernel(Args a)
 #pragma unroll
                 for (int q = 0; q < 8; ++q)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) acc = SZ_MFMA32(w[q][i], xr[mt][q][i], acc);
+                    for (int i = 0; i < 4; ++i) {
+                        if (SZ_INFER_ABLATE & 1) acc[0] += w[q][i] * xr[mt][q][i];
+                        else acc = SZ_MFMA32(w[q][i], xr[mt][q][i], acc);
+                    }
                 float* dst = h1s + (size_t)(32 * mt + l31) * LD + 32 * t1 + 4 * half;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -273,7 +281,10 @@ __global__ __launch_bounds__(kThreads) void infer_vote_kernel(Args a)
 #pragma unroll
                         for (int q = 0; q < 4; ++q)
 #pragma unroll
-                            for (int i = 0; i < 4; ++i) h2[mt] = SZ_MFMA32(wv[q][i], hv[q][i], h2[mt]);
+                            for (int i = 0; i < 4; ++i) {
+                                if (SZ_INFER_ABLATE & 2) h2[mt][0] += wv[q][i] * hv[q][i];
+                                else h2[mt] = SZ_MFMA32(wv[q][i], hv[q][i], h2[mt]);
+                            }
                     }
                     // (keeps the compiler from moving the LDS reads of all four trips to the top, which
                     // costs more registers than there are)
@@ -291,6 +302,10 @@ __global__ __launch_bounds__(kThreads) void infer_vote_kernel(Args a)
             }
         }
         __syncthreads();  // h1 has been read by everyone: its space takes the partial logits
+        if (SZ_INFER_ABLATE & 4) {
+            if (wave < JT && h2[0][0] == 123.456f) atomicAdd(&hist[0], 1u);
+            continue;
+        }
         // ---- 3. output layer: partial logits over the wave's units, then the sum over the waves
         if (wave < JT) {
 #pragma unroll
@@ -355,7 +370,7 @@ __global__ __launch_bounds__(kThreads) void infer_vote_kernel(Args a)
             if (cl + 16 * u < a.C) atomicAdd(&dsum[cl + 16 * u], pacc[u]);
     }
     __syncthreads();
-    if (tid < a.C) {
+    if (tid < a.C && !(SZ_INFER_ABLATE & 8)) {
         if (a.counts && hist[tid]) atomicAdd(&a.counts[tid], (unsigned long long)hist[tid]);
         if (a.psums) atomicAdd(&a.psums[tid], dsum[tid]);
     }
