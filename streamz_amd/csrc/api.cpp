@@ -818,11 +818,13 @@ int szh_identify_from_features(szh_net* net, const float* feats, uint64_t n_wind
 }
 
 // Windows per tile of a long recording; recordings of up to two tiles go through in one piece.
-static uint32_t tile_windows_default()
+// Device-resident PCM through the one-kernel vote has no per-tile intermediates to keep in L2, and larger tiles
+// amortise the launches (100 h, M windows/s: 8192: 220, 32768: 255, 65536: 267, 262144: 274).
+static uint32_t tile_windows_default(bool resident_fused = false)
 {
     const char* v = std::getenv("STREAMZ_TILE_WINDOWS");
     const long long t = v ? std::atoll(v) : 0;
-    return t >= 4 && t <= (1ll << 24) ? (uint32_t)t : 8192u;
+    return t >= 4 && t <= (1ll << 24) ? (uint32_t)t : resident_fused ? 65536u : 8192u;
 }
 
 // Votes and / or probability sums of a recording (host or device PCM), read back to the host.
@@ -960,8 +962,9 @@ int szh_identify_speaker_list_dev(szh_net* net, szh_extractor* ext, const int16_
 {
     SZ_TRY
     if (!net || !ext || !n_ids || (n_samples && !pcm_dev)) { set_error("null argument"); return SZH_EINVAL; }
-    return identify_pcm(reinterpret_cast<Net*>(net), reinterpret_cast<Extractor*>(ext), pcm_dev, true, n_samples,
-                        threshold, tile_windows ? tile_windows : tile_windows_default(), ids, capacity, n_ids, counts);
+    Net* n = reinterpret_cast<Net*>(net);
+    return identify_pcm(n, reinterpret_cast<Extractor*>(ext), pcm_dev, true, n_samples, threshold,
+                        tile_windows ? tile_windows : tile_windows_default(net_vote_fused(n)), ids, capacity, n_ids, counts);
     SZ_CATCH
 }
 

@@ -2162,6 +2162,8 @@ static bool infer_fused_applies(const Net* n)
 }
 
 // the weights in that kernel's fetch order (the workspace must exist)
+bool net_vote_fused(const Net* n) { return infer_fused_applies(n); }
+
 int net_vote_prepare(Net* n, hipStream_t s)
 {
     if (!infer_fused_applies(n)) return SZH_OK;

@@ -129,9 +129,10 @@ int identify_tiled(Net* n, Extractor* e, const int16_t* pcm, bool pcm_on_device,
     if (pcm_on_device && !single && n_mid >= 2 && !prof_enabled()) {
         const char* env_v = std::getenv("STREAMZ_TILE_LANES");
         const int env_lanes = env_v ? std::atoi(env_v) : 0;
-        // three by default: with four, the lanes' streams compete for the process's four hardware queues
-        // (100 h in tiles of 8192 windows: 0.38 s with one lane, 0.24 with two, 0.21 with three, 0.25 with four)
-        max_lanes = env_lanes > 0 ? (uint64_t)std::min(env_lanes, kMaxLanes) : (B <= 65536 ? 3 : 1);
+        // three for small tiles: with four, the lanes' streams compete for the process's four hardware queues
+        // (100 h in tiles of 8192 windows: 0.38 s with one lane, 0.24 with two, 0.21 with three, 0.25 with four);
+        // two for tiles whose kernels fill the chip by themselves (65536 windows: 0.149 s with two, 0.152 with three)
+        max_lanes = env_lanes > 0 ? (uint64_t)std::min(env_lanes, kMaxLanes) : B < 32768 ? 3 : B <= 262144 ? 2 : 1;
     }
     uint64_t feat_rows = single ? nw : std::max<uint64_t>(B * max_lanes, last_rows);
     int rc = net_reserve_rows(n, feat_rows);

@@ -14,7 +14,7 @@ torch.cuda.synchronize()
 net = sz.SimpleNeuralNet(60, 512, 256, 16, seed=7)
 ext = sz.FeatureExtractor()
 ref = None
-for tile in (8192, 32768):
+for tile in [int(t) for t in os.environ.get("TILES", "8192,32768").split(",")]:
     best = None
     for _ in range(3):
         t0 = time.perf_counter()
