@@ -189,6 +189,7 @@ int net_read_totals(Net* n, hipStream_t s, double* loss_sum, double* live_rows);
 int net_vote_dev(Net* n, const float* x_dev, uint64_t rows, float threshold, unsigned long long* counts_dev,
                  double* psums_dev, hipStream_t s, bool tables_prepared = false);
 int net_vote_prepare(Net* n, hipStream_t s);
+bool net_vote_fused(const Net* n);   // the one-kernel vote applies to this net's widths
 // Pooled embedding (un-normalised) of device feature rows, written to host memory out[hidden2]:
 // mode 0 mean of forward_embedding, 1 median of forward_embedding, 2 median of embed.
 int net_pool_host(Net* n, const float* x_dev, uint64_t rows, int mode, float* out);

@@ -2,13 +2,13 @@
 sizes; STREAMZ_NO_FUSED_VOTE=1 selects the per-layer kernels.  usage: python tools/vote_timing.py [classes]"""
 import os, sys, time
 import numpy as np, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import streamz_amd as sz
 classes = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 net = sz.SimpleNeuralNet(60, 512, 256, classes, seed=7)
 flop = 2 * (60 * 512 + 512 * 256 + 256 * classes)
 s = torch.cuda.current_stream().cuda_stream
-for n in (8192, 32768, 262144, 6614000):
+for n in [int(v) for v in os.environ.get("ROWS", "8192,16384,32768,65536,262144,6614000").split(",")]:
     x = torch.randn((n, 60), device="cuda")
     counts = torch.zeros(classes, dtype=torch.int64, device="cuda")
     for _ in range(3):
