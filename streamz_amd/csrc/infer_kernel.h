@@ -10,6 +10,9 @@
 // 3 straight from its accumulators, and only h1, which every wave needs all of, passes through LDS.
 //
 // A workgroup of 8 waves owns MT blocks of 32 rows:
+//   0. the tile's rows come from an LDS buffer that was filled during the previous tile (one coalesced copy of
+//      the tile's contiguous rows, requested before its first layer, stored after it), so that no wave waits
+//      for HBM between tiles;
 //   1. h1^T tiles (32 units x 32 rows, K = 64: the inputs, a one for the bias, zeros) are dealt to the
 //      waves; ReLU; written to LDS as h1[row][unit] (16-byte pieces, conflict-free);
 //   2. wave w computes h2^T for units 32 w .. 32 w + 31 over all of h1: its rows of w2^T come straight
@@ -65,7 +68,11 @@ inline size_t act_floats(int mt, int h1, int nct)
     const size_t h = (size_t)mt * 32 * (h1 + 4), p = (size_t)kWaves * mt * 32 * part_ld(nct);
     return h > p ? h : p;
 }
-inline size_t lds_bytes(int mt, int h1, int nct) { return act_floats(mt, h1, nct) * sizeof(float) + kMaxClasses * (sizeof(unsigned int) + sizeof(double)); }
+// ... plus the vote histogram, the probability sums and the staging buffer of the next tile's rows
+inline size_t lds_bytes(int mt, int h1, int nct, int in)
+{
+    return act_floats(mt, h1, nct) * sizeof(float) + kMaxClasses * (sizeof(unsigned int) + sizeof(double)) + (size_t)mt * 32 * in * sizeof(float);
+}
 
 inline size_t table_floats(int h1, int h2) { return (size_t)h1 * 64 + (size_t)h2 * h1 + (size_t)kMaxClasses * h2; }
 
@@ -133,7 +140,8 @@ __device__ __forceinline__ f32x4v load_frag(__amdgpu_buffer_rsrc_t tab, unsigned
 
 #define SZ_MFMA32(a_, b_, c_) __builtin_amdgcn_mfma_f32_32x32x2f32((a_), (b_), (c_), 0, 0, 0)
 // tools/infer_bench.hip builds timing-only variants with parts of a tile left out (bit 1: the first
-// layer's matrix instructions, 2: the second layer's, 4: output layer, softmax and vote, 8: the final global atomics)
+// layer's matrix instructions, 2: the second layer's, 4: output layer, softmax and vote, 8: the final global
+// atomics, 16: every tile reads the first rows (no HBM latency), 32: no tanh, 64: no softmax arithmetic)
 #ifndef SZ_INFER_ABLATE
 #define SZ_INFER_ABLATE 0
 #endif
@@ -148,6 +156,7 @@ __global__ __launch_bounds__(kThreads) void infer_vote_kernel(Args a)
     float* h1s = ilds;   // [MT * 32][LD]; later the partial logits [wave][MT][32 rows][PLD]
     unsigned int* hist = reinterpret_cast<unsigned int*>(ilds + a.tail_off);  // [64]
     double* dsum = reinterpret_cast<double*>(hist + kMaxClasses);             // [64] (8-byte aligned: tail_off is even)
+    float* xs = reinterpret_cast<float*>(dsum + kMaxClasses);                 // [MT * 32][in]: the rows of the tile to come
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, half = lane >> 5;
@@ -163,27 +172,58 @@ __global__ __launch_bounds__(kThreads) void infer_vote_kernel(Args a)
     float b3v[2 * NCT];
 #pragma unroll
     for (int u = 0; u < 2 * NCT; ++u) b3v[u] = cl + 16 * u < a.C ? a.b3[cl + 16 * u] : 0.0f;
-    __syncthreads();
 
     const uint64_t n_tiles = (a.rows + 32 * MT - 1) / (32 * MT);
+    // A tile's rows are contiguous in memory: 8 MT in 16-byte pieces, piece e of the tile by thread e % 512.
+    // Pieces behind the last row repeat the last piece (their rows' results are not counted).
+    const uint32_t tile_pieces = 8u * MT * (uint32_t)a.in;
+    const uint64_t last_piece = a.rows * (uint64_t)a.in / 4 - 1;
+    f32x4v xn[MT];
+    auto fetch_rows = [&](uint64_t t) {
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+            const uint32_t e = (uint32_t)tid + kThreads * j;
+            uint64_t g = ((SZ_INFER_ABLATE & 16) ? 0 : t) * tile_pieces + e;
+            g = g < last_piece ? g : last_piece;
+            if (e < tile_pieces) xn[j] = reinterpret_cast<const f32x4v*>(a.x)[g];
+        }
+    };
+    auto stage_rows = [&]() {
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+            const uint32_t e = (uint32_t)tid + kThreads * j;
+            if (e < tile_pieces) reinterpret_cast<f32x4v*>(xs)[e] = xn[j];
+        }
+    };
+    if (blockIdx.x < n_tiles) { fetch_rows(blockIdx.x); stage_rows(); }
+    __syncthreads();
+
     for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const uint64_t row0 = tile * (32 * MT);
-        // Everything this tile reads from global memory is requested up front, so that the latencies of
-        // the rows, of the first layer's weights and of the second layer's first trips overlap.
+        // The tile's rows from the staging buffer; the weights of the first layer and of the second layer's
+        // first trips are requested up front.
         f32x4v xr[MT][8];  // lane (m, half): x[m][32 half + 4 q + 0..3]
+        // (in is a multiple of 4: a group of four lies inside the row, or starts with the bias's one, or is padding)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            const uint64_t r = row0 + 32 * mt + l31;
-            const float* xp = a.x + (r < a.rows ? r : a.rows - 1) * (uint64_t)a.in;
+            const float* xp = xs + (32 * mt + l31) * a.in;
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const int c0 = 32 * half + 4 * q;
-                // (in is a multiple of 4: a group of four lies inside the row, or starts with the bias's one, or is padding)
-                f32x4v v = {c0 == a.in ? 1.0f : 0.0f, 0.0f, 0.0f, 0.0f};
-                if (c0 < a.in) v = *reinterpret_cast<const f32x4v*>(xp + c0);
-                xr[mt][q] = v;
+                xr[mt][q] = *reinterpret_cast<const f32x4v*>(xp + (c0 < a.in ? c0 : a.in - 4));
             }
         }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int c0 = 32 * half + 4 * q;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) xr[mt][q][i] = c0 < a.in ? xr[mt][q][i] : 0.0f;
+                xr[mt][q][0] = c0 == a.in ? 1.0f : xr[mt][q][0];
+            }
+        const uint64_t next_tile = tile + gridDim.x;
+        if (next_tile < n_tiles) fetch_rows(next_tile);
         const unsigned boff = (unsigned)lane * 16u;
         // the wave's tiles of the first layer's weights, two in flight
         f32x4v wa0[8], wa1[8];
@@ -196,8 +236,9 @@ __global__ __launch_bounds__(kThreads) void infer_vote_kernel(Args a)
             for (int q = 0; q < 8; ++q) wa1[q] = load_frag(tab, 8192u * (wave + kWaves), boff + 1024u * q);
         }
         const unsigned w2_off = 256u * H1 + 4096u * (unsigned)(wave * KT);  // bytes to the wave's first trip of w2f; 4096 per trip
-        f32x4v wb[4][4];  // the second layer's weights, four trips of 32 units in flight (two of them from here on)
-        constexpr int EARLY = MT == 1 ? 2 : 0;
+        constexpr int D = 2;  // trips of the second layer's weights in flight (a trip is 16 MT matrix instructions)
+        f32x4v wb[D][4];
+        constexpr int EARLY = MT == 1 ? D : 0;  // ... of which these are requested ahead of the first layer
         if (wave < JT) {
 #pragma unroll
             for (int d = 0; d < EARLY; ++d)
@@ -244,34 +285,33 @@ __global__ __launch_bounds__(kThreads) void infer_vote_kernel(Args a)
         }
         if (wave < JT) {
 #pragma unroll
-            for (int d = EARLY; d < 4; ++d)
+            for (int d = EARLY; d < D; ++d)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) wb[d][q] = load_frag(tab, w2_off + 4096u * d, boff + 1024u * q);
         }
         __syncthreads();
+        // Every wave has taken this tile's rows out of the staging buffer: the next tile's go in.  They were
+        // requested before the first layer (loads complete in order, so a request made here would be waited
+        // for by the second layer's first weight fragments).
+        if (next_tile < n_tiles) stage_rows();
         // ---- 2. second layer: the wave's 32 units of h2, over all of h1
         f32x16 h2[MT];
         f32x4v w3v[NCT][4];  // the output layer's weights for this wave's units
         if (wave < JT) {
 #pragma unroll
-            for (int ct = 0; ct < NCT; ++ct)
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    w3v[ct][q] = load_frag(tab, w3_off + 4096u * (unsigned)(ct * JT + wave), boff + 1024u * q);
-#pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) h2[mt][r] = 0.0f;
             const float* hp = h1s + (size_t)l31 * LD + 4 * half;
-            for (int ko = 0; ko < KT; ko += 4) {
+            for (int ko = 0; ko < KT; ko += D) {
 #pragma unroll
-                for (int d = 0; d < 4; ++d) {
+                for (int d = 0; d < D; ++d) {
                     f32x4v wv[4];
 #pragma unroll
                     for (int q = 0; q < 4; ++q) wv[q] = wb[d][q];
-                    if (ko + 4 + d < KT) {
+                    if (ko + D + d < KT) {
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) wb[d][q] = load_frag(tab, w2_off + 4096u * (ko + 4 + d), boff + 1024u * q);
+                        for (int q = 0; q < 4; ++q) wb[d][q] = load_frag(tab, w2_off + 4096u * (ko + D + d), boff + 1024u * q);
                     }
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) {
@@ -291,6 +331,12 @@ __global__ __launch_bounds__(kThreads) void infer_vote_kernel(Args a)
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
+            // (requested here, where the second layer's weight registers have become free; the tanh covers the wait)
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    w3v[ct][q] = load_frag(tab, w3_off + 4096u * (unsigned)(ct * JT + wave), boff + 1024u * q);
             // bias and tanh (lib.rs:883); register 4 q + i is unit 32 wave + 8 q + 4 half + i
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -298,7 +344,8 @@ __global__ __launch_bounds__(kThreads) void infer_vote_kernel(Args a)
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) h2[mt][4 * q + i] = gemm::fast_tanh(h2[mt][4 * q + i] + bv[i]);
+                    for (int i = 0; i < 4; ++i)
+                        h2[mt][4 * q + i] = (SZ_INFER_ABLATE & 32) ? h2[mt][4 * q + i] + bv[i] : gemm::fast_tanh(h2[mt][4 * q + i] + bv[i]);
             }
         }
         __syncthreads();  // h1 has been read by everyone: its space takes the partial logits
@@ -331,6 +378,7 @@ __global__ __launch_bounds__(kThreads) void infer_vote_kernel(Args a)
         __syncthreads();
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
+            if (SZ_INFER_ABLATE & 64) continue;
             const uint64_t row = row0 + 32 * mt + rm;
             const bool row_ok = row < a.rows;
             float v[2 * NCT];
@@ -339,7 +387,11 @@ __global__ __launch_bounds__(kThreads) void infer_vote_kernel(Args a)
             for (int u = 0; u < 2 * NCT; ++u) {
                 const int c = cl + 16 * u;
                 float s = b3v[u];
-                for (int w = 0; w < JT; ++w) s += h1s[(size_t)((w * MT + mt) * 32 + rm) * PLD + c];
+                float part[kWaves];  // (all requested before the first is added)
+#pragma unroll
+                for (int w = 0; w < kWaves; ++w) part[w] = h1s[(size_t)(((w < JT ? w : 0) * MT + mt) * 32 + rm) * PLD + c];
+#pragma unroll
+                for (int w = 0; w < kWaves; ++w) s += w < JT ? part[w] : 0.0f;
                 v[u] = c < a.C ? s : -INFINITY;
                 mx = fmaxf(mx, v[u]);
             }

@@ -2202,9 +2202,9 @@ static int launch_infer_vote(Net* n, const float* x_dev, uint64_t rows, float th
     const int nct = n->out <= 32 ? 1 : 2;
     // two blocks of 32 rows per workgroup (every weight fragment used twice) once that still leaves
     // every compute unit two tiles
-    const int mt = (rows >= 128ull * compute_units() && infer::lds_bytes(2, a.H1, nct) <= 150 * 1024) ? 2 : 1;
+    const int mt = (rows >= 128ull * compute_units() && infer::lds_bytes(2, a.H1, nct, a.in) <= 156 * 1024) ? 2 : 1;
     a.tail_off = (int)infer::act_floats(mt, a.H1, nct);
-    const size_t lds = infer::lds_bytes(mt, a.H1, nct);
+    const size_t lds = infer::lds_bytes(mt, a.H1, nct, a.in);
     if (mt == 2) return nct == 1 ? launch_infer_vote_one<2, 1>(a, lds, s) : launch_infer_vote_one<2, 2>(a, lds, s);
     return nct == 1 ? launch_infer_vote_one<1, 1>(a, lds, s) : launch_infer_vote_one<1, 2>(a, lds, s);
 }

@@ -1,6 +1,6 @@
 // Timing harness of the fused vote kernel (streamz_amd/csrc/infer_kernel.h) on random tables, for ablations:
 // build with -DSZ_INFER_ABLATE=<bits> (1: no first-layer MFMAs, 2: no second-layer MFMAs, 4: no output layer /
-// softmax / vote) to see what each part of a tile costs.  Results of an ablated build are meaningless.
+// softmax / vote, 8, 16, 32, 64: see infer_kernel.h) to see what each part of a tile costs.  Results of an ablated build are meaningless.
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -I../streamz_amd/csrc -I../include -o infer_bench infer_bench.hip
 //   ./infer_bench [rows] [mt]
 #include <hip/hip_runtime.h>
@@ -36,7 +36,7 @@ int main(int argc, char** argv)
     Args a{};
     a.x = dx; a.rows = rows; a.in = in; a.tab = dt; a.b2 = db; a.b3 = db + H2; a.H1 = H1; a.H2 = H2; a.C = C; a.threshold = 0.1f;
     a.counts = dc; a.psums = nullptr; a.tail_off = (int)act_floats(mt, H1, 1);
-    const size_t lds = lds_bytes(mt, H1, 1);
+    const size_t lds = lds_bytes(mt, H1, 1, in);
     const void* fn = mt == 2 ? (const void*)infer_vote_kernel<2, 1> : (const void*)infer_vote_kernel<1, 1>;
     HK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const uint64_t tiles = (rows + 32 * mt - 1) / (32 * mt);
