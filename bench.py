@@ -164,7 +164,7 @@ def other_figures(sz, ext, plan, pcm, feats, net_dims, n_win, dev, lr, dropout):
     sz.pretrain_from_features(net, host, 1, net_dims[3], b8_epochs, lr, dropout, 8, seed=2)
     t_b8 = (time.perf_counter() - t0) / b8_epochs
     # the inference-only configuration: a 100 h recording (39 689 999 windows) already in device
-    # memory, identify_speaker_list in tiles (65536 windows by default) replayed from a HIP graph
+    # memory, identify_speaker_list in tiles (262144 windows by default) replayed from a HIP graph
     n_stream = 100 * 3600 * 44100
     block = pcm[:400 * 3000]
     rec = block.repeat((n_stream + block.numel() - 1) // block.numel())[:n_stream].contiguous()
@@ -188,7 +188,7 @@ def other_figures(sz, ext, plan, pcm, feats, net_dims, n_win, dev, lr, dropout):
                                                     "whole call (extraction of every tile included) against the f32 matrix peak"),
             "infer_roofline": mfma_roofline(n_win / t_inf, "extract + vote over all clips against the f32 matrix peak"),
             "identify_100h_seconds": t_stream,
-            "identify_100h_note": "configs[3]: identify_speaker_list over 100 h of PCM resident in HBM, tiles of 65536 "
+            "identify_100h_note": "configs[3]: identify_speaker_list over 100 h of PCM resident in HBM, tiles of 262144 "
                                   "windows, one HIP graph replay per tile, votes read once at the end",
             "infer_windows_per_s": n_win / t_inf,
             "infer_note": "extract + forward + thresholded vote (lib.rs:1383-1411) over all clips, device-resident",

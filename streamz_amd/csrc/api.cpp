@@ -819,12 +819,12 @@ int szh_identify_from_features(szh_net* net, const float* feats, uint64_t n_wind
 
 // Windows per tile of a long recording; recordings of up to two tiles go through in one piece.
 // Device-resident PCM through the one-kernel vote has no per-tile intermediates to keep in L2, and larger tiles
-// amortise the launches (100 h, M windows/s: 8192: 220, 32768: 255, 65536: 267, 262144: 274).
+// amortise the launches (100 h, M windows/s: 8192: 250, 65536: 292, 262144: 300).
 static uint32_t tile_windows_default(bool resident_fused = false)
 {
     const char* v = std::getenv("STREAMZ_TILE_WINDOWS");
     const long long t = v ? std::atoll(v) : 0;
-    return t >= 4 && t <= (1ll << 24) ? (uint32_t)t : resident_fused ? 65536u : 8192u;
+    return t >= 4 && t <= (1ll << 24) ? (uint32_t)t : resident_fused ? 262144u : 8192u;
 }
 
 // Votes and / or probability sums of a recording (host or device PCM), read back to the host.

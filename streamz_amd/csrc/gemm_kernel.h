@@ -61,13 +61,14 @@ struct GemmArgs {
 
 struct Frag4 { float v[4]; };
 
-// tanh from the hardware exponential; absolute error ~1e-7; a NaN stays a NaN (the clamp alone would
-// turn it into -1, where the reference's tanh, lib.rs:883, carries it on)
+// tanh from the hardware exponential and reciprocal (1 ulp each); absolute error ~1e-7.  No clamp and no
+// special cases are needed: e^(2x) overflows to +inf (1 - 2/inf = 1) or underflows to 0 (1 - 2/1 = -1) exactly where
+// the result has long rounded to +-1, and a NaN goes through both instructions as a NaN (the reference's tanh,
+// lib.rs:883, carries it on too)
 __device__ __forceinline__ float fast_tanh(float x)
 {
-    const float t = __expf(2.0f * fminf(fmaxf(x, -15.0f), 15.0f));
-    const float y = 1.0f - 2.0f * __builtin_amdgcn_rcpf(t + 1.0f);  // v_rcp_f32: 1 ulp
-    return x != x ? x : y;
+    const float t = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);  // 2^(x * 2 log2 e) = e^(2x)
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(t + 1.0f);
 }
 
 __device__ __forceinline__ Frag4 load4(const float* base, int64_t row, int col, int ld, int row_max, int col_max,

@@ -138,6 +138,20 @@ __device__ __forceinline__ f32x4v load_frag(__amdgpu_buffer_rsrc_t tab, unsigned
     return __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(tab, lane_bytes, uniform_bytes, 0));
 }
 
+// max(v, 0) as the one instruction it is (v > 0 ? v : 0 in source costs a second one that quiets NaNs first;
+// v_max_f32 returns the other operand for a NaN, which is what lib.rs:882 does with one)
+__device__ __forceinline__ float relu(float v)
+{
+    float r;
+    asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(v));
+    return r;
+}
+#ifndef SZ_INFER_D1
+#define SZ_INFER_D1 2
+#endif
+#ifndef SZ_INFER_D2
+#define SZ_INFER_D2 2
+#endif
 #define SZ_MFMA32(a_, b_, c_) __builtin_amdgcn_mfma_f32_32x32x2f32((a_), (b_), (c_), 0, 0, 0)
 // tools/infer_bench.hip builds timing-only variants with parts of a tile left out (bit 1: the first
 // layer's matrix instructions, 2: the second layer's, 4: output layer, softmax and vote, 8: the final global
@@ -226,25 +240,26 @@ __global__ __launch_bounds__(kThreads) void infer_vote_kernel(Args a)
         if (next_tile < n_tiles) fetch_rows(next_tile);
         const unsigned boff = (unsigned)lane * 16u;
         // the wave's tiles of the first layer's weights, two in flight
+        // (A wave without a tile or a unit block of its own requests the last one's weights and does not use
+        // them: requests under a condition would make every one of these registers a value carried round the
+        // tile loop, kept alive and copied.)
         f32x4v wa0[8], wa1[8];
-        if (wave < KT) {
+        {
+            const int ta = wave < KT ? wave : KT - 1, tb = wave + kWaves < KT ? wave + kWaves : KT - 1;
 #pragma unroll
-            for (int q = 0; q < 8; ++q) wa0[q] = load_frag(tab, 8192u * wave, boff + 1024u * q);
-        }
-        if (wave + kWaves < KT) {
+            for (int q = 0; q < 8; ++q) wa0[q] = load_frag(tab, 8192u * ta, boff + 1024u * q);
 #pragma unroll
-            for (int q = 0; q < 8; ++q) wa1[q] = load_frag(tab, 8192u * (wave + kWaves), boff + 1024u * q);
+            for (int q = 0; q < 8; ++q) wa1[q] = load_frag(tab, 8192u * tb, boff + 1024u * q);
         }
-        const unsigned w2_off = 256u * H1 + 4096u * (unsigned)(wave * KT);  // bytes to the wave's first trip of w2f; 4096 per trip
-        constexpr int D = 2;  // trips of the second layer's weights in flight (a trip is 16 MT matrix instructions)
+        const int jw = wave < JT ? wave : JT - 1;  // the wave's block of 32 second-layer units
+        const unsigned w2_off = 256u * H1 + 4096u * (unsigned)(jw * KT);  // bytes to the wave's first trip of w2f; 4096 per trip
+        constexpr int D = MT == 1 ? SZ_INFER_D1 : SZ_INFER_D2;  // trips of the second layer's weights in flight (a trip is 16 MT matrix instructions)
         f32x4v wb[D][4];
         constexpr int EARLY = MT == 1 ? D : 0;  // ... of which these are requested ahead of the first layer
-        if (wave < JT) {
 #pragma unroll
-            for (int d = 0; d < EARLY; ++d)
+        for (int d = 0; d < EARLY; ++d)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) wb[d][q] = load_frag(tab, w2_off + 4096u * d, boff + 1024u * q);
-        }
+            for (int q = 0; q < 4; ++q) wb[d][q] = load_frag(tab, w2_off + 4096u * d, boff + 1024u * q);
         // ---- 1. first layer: h1 = relu([x | 1 | 0] . w1p^T)
         auto layer1_tile = [&](int t1, const f32x4v (&w)[8]) {
 #pragma unroll
@@ -264,7 +279,7 @@ __global__ __launch_bounds__(kThreads) void infer_vote_kernel(Args a)
                 for (int q = 0; q < 4; ++q) {
                     f32x4v o;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) { const float v = acc[4 * q + i]; o[i] = v > 0.0f ? v : 0.0f; }
+                    for (int i = 0; i < 4; ++i) o[i] = relu(acc[4 * q + i]);
                     *reinterpret_cast<f32x4v*>(dst + 8 * q) = o;
                 }
             }
@@ -283,12 +298,10 @@ __global__ __launch_bounds__(kThreads) void infer_vote_kernel(Args a)
                 }
             }
         }
-        if (wave < JT) {
 #pragma unroll
-            for (int d = EARLY; d < D; ++d)
+        for (int d = EARLY; d < D; ++d)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) wb[d][q] = load_frag(tab, w2_off + 4096u * d, boff + 1024u * q);
-        }
+            for (int q = 0; q < 4; ++q) wb[d][q] = load_frag(tab, w2_off + 4096u * d, boff + 1024u * q);
         __syncthreads();
         // Every wave has taken this tile's rows out of the staging buffer: the next tile's go in.  They were
         // requested before the first layer (loads complete in order, so a request made here would be waited
@@ -303,31 +316,49 @@ __global__ __launch_bounds__(kThreads) void infer_vote_kernel(Args a)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) h2[mt][r] = 0.0f;
             const float* hp = h1s + (size_t)l31 * LD + 4 * half;
+            // The activations of a (trip, row block) step are read from LDS one step ahead, while the matrix
+            // instructions of the step before them are being issued: hv[s & 1] belongs to step s.
+            f32x4v hv[2][4];
+            auto read_h = [&](f32x4v (&dst)[4], int trip, int mt) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) dst[q] = *reinterpret_cast<const f32x4v*>(hp + (size_t)(32 * mt) * LD + 32 * trip + 8 * q);
+            };
+            auto multiply = [&](const f32x4v (&w)[4], const f32x4v (&h)[4], f32x16& acc) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        if (SZ_INFER_ABLATE & 2) acc[0] += w[q][i] * h[q][i];
+                        else acc = SZ_MFMA32(w[q][i], h[q][i], acc);
+                    }
+            };
+            read_h(hv[0], 0, 0);
             for (int ko = 0; ko < KT; ko += D) {
 #pragma unroll
                 for (int d = 0; d < D; ++d) {
-                    f32x4v wv[4];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) wv[q] = wb[d][q];
-                    if (ko + D + d < KT) {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) wb[d][q] = load_frag(tab, w2_off + 4096u * (ko + D + d), boff + 1024u * q);
+                    const int trip = ko + d;
+                    if (MT == 1) {
+                        // (D is even, so a trip's buffer is d & 1)
+                        if (trip + 1 < KT) read_h(hv[(d + 1) & 1], trip + 1, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                        multiply(wb[d], hv[d & 1], h2[0]);
+                    } else {
+                        read_h(hv[1], trip, 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                        multiply(wb[d], hv[0], h2[0]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (trip + 1 < KT) read_h(hv[0], trip + 1, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                        multiply(wb[d], hv[1], h2[MT - 1]);
                     }
+                    // the trip D further on, into the registers this one has just been multiplied from (asked
+                    // for any earlier, the compiler copies the fragment it is still using)
+                    if (trip + D < KT) {
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) {
-                        f32x4v hv[4];
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) hv[q] = *reinterpret_cast<const f32x4v*>(hp + (size_t)(32 * mt) * LD + 32 * (ko + d) + 8 * q);
-#pragma unroll
-                        for (int q = 0; q < 4; ++q)
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) {
-                                if (SZ_INFER_ABLATE & 2) h2[mt][0] += wv[q][i] * hv[q][i];
-                                else h2[mt] = SZ_MFMA32(wv[q][i], hv[q][i], h2[mt]);
-                            }
+                        for (int q = 0; q < 4; ++q) wb[d][q] = load_frag(tab, w2_off + 4096u * (trip + D), boff + 1024u * q);
                     }
-                    // (keeps the compiler from moving the LDS reads of all four trips to the top, which
-                    // costs more registers than there are)
+                    // (keeps the compiler from moving the LDS reads of all trips to the top, which costs more
+                    // registers than there are)
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -336,7 +367,7 @@ __global__ __launch_bounds__(kThreads) void infer_vote_kernel(Args a)
             for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                    w3v[ct][q] = load_frag(tab, w3_off + 4096u * (unsigned)(ct * JT + wave), boff + 1024u * q);
+                    w3v[ct][q] = load_frag(tab, w3_off + 4096u * (unsigned)(ct * JT + jw), boff + 1024u * q);
             // bias and tanh (lib.rs:883); register 4 q + i is unit 32 wave + 8 q + 4 half + i
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
