@@ -71,6 +71,15 @@ __device__ __forceinline__ float fast_tanh(float x)
     return 1.0f - 2.0f * __builtin_amdgcn_rcpf(t + 1.0f);
 }
 
+// v > 0 ? v : 0 (lib.rs:882) as the one instruction it is: v_max_f32 returns the other operand for a NaN, and
+// written in source the compiler first spends a second instruction on quieting one
+__device__ __forceinline__ float relu_max(float v)
+{
+    float r;
+    asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(v));
+    return r;
+}
+
 __device__ __forceinline__ Frag4 load4(const float* base, int64_t row, int col, int ld, int row_max, int col_max,
                                        int vec)
 {
@@ -229,6 +238,7 @@ __device__ __forceinline__ void finish_values(const GemmArgs& g, f32x16 (&acc)[2
             const float bias = biasv[tn];
             const size_t mask_at = (size_t)((m0 + wm * 64 + tm * 32) >> 5) * g.N + col;
             uint32_t mword = mwordv[tm][tn];
+            const uint32_t mhalf = mwordv[tm][tn] >> (4 * half);  // EPI_MUL_MASK: this lane's 16 rows are bits rofs of it
             if (EPI == EPI_BIAS_RELU_MASK) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
@@ -242,12 +252,12 @@ __device__ __forceinline__ void finish_values(const GemmArgs& g, f32x16 (&acc)[2
                 const int rofs = (r & 3) + 8 * (r >> 2);
                 const int row = min(row_base + rofs, g.M - 1);  // clamped: only used to read aux
                 float v = acc[tm][tn][r];
-                if (EPI == EPI_BIAS_RELU_MASK || EPI == EPI_BIAS_RELU) { v += bias; v = v > 0.0f ? v : 0.0f; }
+                if (EPI == EPI_BIAS_RELU_MASK || EPI == EPI_BIAS_RELU) v = relu_max(v + bias);
                 else if (EPI == EPI_BIAS_TANH) v = fast_tanh(v + bias);
                 else if (EPI == EPI_BIAS) v += bias;
                 else if (EPI == EPI_MUL_DTANH) { const float h = g.aux[(size_t)row * g.ldaux + col]; v *= (1.0f - h * h); }
                 else if (EPI == EPI_MUL_DRELU) { const float h = g.aux[(size_t)row * g.ldaux + col]; v *= (h > 0.0f ? 1.0f : 0.0f); }
-                else if (EPI == EPI_MUL_MASK) v *= ((mword >> (rofs + 4 * half)) & 1u) ? 1.0f : 0.0f;  // a product, as lib.rs:1039-1040: 0 x NaN stays NaN
+                else if (EPI == EPI_MUL_MASK) v *= (float)((mhalf >> rofs) & 1u);  // a product, as lib.rs:1039-1040: 0 x NaN stays NaN (bit field extract, convert, multiply)
                 acc[tm][tn][r] = v;
             }
         }

@@ -138,20 +138,6 @@ __device__ __forceinline__ f32x4v load_frag(__amdgpu_buffer_rsrc_t tab, unsigned
     return __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(tab, lane_bytes, uniform_bytes, 0));
 }
 
-// max(v, 0) as the one instruction it is (v > 0 ? v : 0 in source costs a second one that quiets NaNs first;
-// v_max_f32 returns the other operand for a NaN, which is what lib.rs:882 does with one)
-__device__ __forceinline__ float relu(float v)
-{
-    float r;
-    asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(v));
-    return r;
-}
-#ifndef SZ_INFER_D1
-#define SZ_INFER_D1 2
-#endif
-#ifndef SZ_INFER_D2
-#define SZ_INFER_D2 2
-#endif
 #define SZ_MFMA32(a_, b_, c_) __builtin_amdgcn_mfma_f32_32x32x2f32((a_), (b_), (c_), 0, 0, 0)
 // tools/infer_bench.hip builds timing-only variants with parts of a tile left out (bit 1: the first
 // layer's matrix instructions, 2: the second layer's, 4: output layer, softmax and vote, 8: the final global
@@ -253,7 +239,7 @@ __global__ __launch_bounds__(kThreads) void infer_vote_kernel(Args a)
         }
         const int jw = wave < JT ? wave : JT - 1;  // the wave's block of 32 second-layer units
         const unsigned w2_off = 256u * H1 + 4096u * (unsigned)(jw * KT);  // bytes to the wave's first trip of w2f; 4096 per trip
-        constexpr int D = MT == 1 ? SZ_INFER_D1 : SZ_INFER_D2;  // trips of the second layer's weights in flight (a trip is 16 MT matrix instructions)
+        constexpr int D = 2;  // trips of the second layer's weights in flight (a trip is 16 MT matrix instructions)
         f32x4v wb[D][4];
         constexpr int EARLY = MT == 1 ? D : 0;  // ... of which these are requested ahead of the first layer
 #pragma unroll
@@ -279,7 +265,7 @@ __global__ __launch_bounds__(kThreads) void infer_vote_kernel(Args a)
                 for (int q = 0; q < 4; ++q) {
                     f32x4v o;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) o[i] = relu(acc[4 * q + i]);
+                    for (int i = 0; i < 4; ++i) o[i] = gemm::relu_max(acc[4 * q + i]);
                     *reinterpret_cast<f32x4v*>(dst + 8 * q) = o;
                 }
             }
