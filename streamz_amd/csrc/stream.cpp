@@ -135,9 +135,11 @@ int identify_tiled(Net* n, Extractor* e, const int16_t* pcm, bool pcm_on_device,
         max_lanes = env_lanes > 0 ? (uint64_t)std::min(env_lanes, kMaxLanes) : B < 32768 ? 3 : B <= 262144 ? 2 : 1;
     }
     uint64_t feat_rows = single ? nw : std::max<uint64_t>(B * max_lanes, last_rows);
-    int rc = net_reserve_rows(n, feat_rows);
+    // (the one-kernel vote keeps no activations in memory: its net needs no rows of workspace beyond the minimum)
+    const bool fused = net_vote_fused(n);
+    int rc = net_reserve_rows(n, fused ? 256 : feat_rows);
     if (rc) return rc;
-    if (max_lanes > 1 && net_workspace_rows(n) < B * max_lanes) {   // the reservation was capped
+    if (!fused && max_lanes > 1 && net_workspace_rows(n) < B * max_lanes) {   // the reservation was capped
         max_lanes = std::max<uint64_t>(1, net_workspace_rows(n) / B);
         feat_rows = std::max<uint64_t>(B * max_lanes, last_rows);
     }
