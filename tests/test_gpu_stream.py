@@ -131,7 +131,7 @@ def test_profiled_run_gives_the_same_votes(sz, nets):
 
 def test_100h_stream_by_periodicity(sz, nets):
     """The inference-only configuration at full size: 100 h of 44.1 kHz PCM (39 689 999 windows)
-    in tiles of 8192 windows.  The recording repeats a block of P windows' worth of samples, so
+    in tiles of 8192 windows and in the library's default tiles.  The recording repeats a block of P windows' worth of samples, so
     every interior window w has the features of window w + P, and the votes of n windows obey
     c(R*P + k) = c(P + k) + (R - 1) * (c(2P + k) - c(P + k)) exactly."""
     import torch
@@ -161,6 +161,10 @@ def test_100h_stream_by_periodicity(sz, nets):
     np.testing.assert_array_equal(full.astype(np.int64), c1 + (R - 1) * (c2 - c1))
     order = sorted((i for i in range(16) if full[i] > 0), key=lambda i: (-int(full[i]), i))
     assert ids == order
+    # the library's own tile size (tile_windows 0: larger tiles, two rows blocks per workgroup of the vote kernel)
+    ids0, full0 = sz.identify_speaker_list_dev(net, stream.data_ptr(), n_samples, thr, ext)
+    np.testing.assert_array_equal(full0, full)
+    assert ids0 == ids
     # every window is counted exactly once when the threshold lets all of them vote
     _, everyone = sz.identify_speaker_list_dev(net, stream.data_ptr(), n_samples, 0.0, ext, tile_windows=8192)
     assert int(everyone.sum()) == nw
