@@ -836,17 +836,24 @@ static int tally_pcm(Net* n, Extractor* e, const int16_t* pcm, bool on_device, u
     if (counts) counts->assign(n->out, 0);
     if (sums) sums->assign(n->out, 0.0);
     if (n->out == 0 || szh_window_count(n_samples) == 0) return SZH_OK;
-    DevBuf d_cnt, d_sum;
-    int rc = d_cnt.alloc(n->out * sizeof(unsigned long long));
-    if (rc == SZH_OK) rc = d_sum.alloc(n->out * sizeof(double));
+    // votes and probability sums side by side in the net's staging buffer (the mutex is held): one clear, one read
+    void* d_tally = nullptr;
+    const size_t cnt_bytes = n->out * sizeof(unsigned long long), sum_bytes = n->out * sizeof(double);
+    int rc = net_stage_dev(n, 3, cnt_bytes + sum_bytes, &d_tally);
     if (rc) return rc;
-    SZ_HIP(hipMemset(d_cnt.p, 0, n->out * sizeof(unsigned long long)));
-    SZ_HIP(hipMemset(d_sum.p, 0, n->out * sizeof(double)));
-    rc = identify_tiled(n, e, pcm, on_device, n_samples, threshold, tile, counts ? d_cnt.as<unsigned long long>() : nullptr,
-                        sums ? d_sum.as<double>() : nullptr);
+    unsigned long long* d_cnt = static_cast<unsigned long long*>(d_tally);
+    double* d_sum = reinterpret_cast<double*>(static_cast<char*>(d_tally) + cnt_bytes);
+    // cleared on the stream the first tile's kernels run on (identify_tiled takes the same one from the net)
+    hipStream_t compute = nullptr, copy = nullptr;
+    rc = net_keep_streams(n, &compute, &copy);
     if (rc) return rc;
-    if (counts) SZ_HIP(hipMemcpy(counts->data(), d_cnt.p, n->out * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    if (sums) SZ_HIP(hipMemcpy(sums->data(), d_sum.p, n->out * sizeof(double), hipMemcpyDeviceToHost));
+    SZ_HIP(hipMemsetAsync(d_tally, 0, cnt_bytes + sum_bytes, compute));
+    rc = identify_tiled(n, e, pcm, on_device, n_samples, threshold, tile, counts ? d_cnt : nullptr, sums ? d_sum : nullptr);
+    if (rc) return rc;
+    std::vector<unsigned char> host(cnt_bytes + sum_bytes);
+    SZ_HIP(hipMemcpy(host.data(), d_tally, host.size(), hipMemcpyDeviceToHost));
+    if (counts) std::memcpy(counts->data(), host.data(), cnt_bytes);
+    if (sums) std::memcpy(sums->data(), host.data() + cnt_bytes, sum_bytes);
     return SZH_OK;
 }
 

@@ -120,6 +120,14 @@ struct Net {
     std::mutex mu;              // serialises host-API calls that share the workspace
     Workspace ws;
     Staging stage;              // guarded by mu
+    // What identify_speaker* keeps between calls (guarded by mu): two streams, and the buffers of recordings
+    // short enough to go through in one piece -- a call on a one-second clip otherwise spends most of its time
+    // creating and destroying them.
+    struct IdentifyKeep {
+        hipStream_t compute = nullptr, copy = nullptr;
+        void* buf[3] = {};       // features, two PCM staging buffers
+        size_t cap[3] = {};
+    } keep;
     int device = 0;
     int gemm_mode = 0;          // SZH_GEMM_*: arithmetic of the large batched products
     // metadata carried by model.npz (lib.rs:755-761)
@@ -200,6 +208,9 @@ uint64_t net_workspace_rows(const Net* n);
 // device buffer `slot` of at least `bytes` (grow-only, owned by the net; call with n->mu held)
 int net_stage_dev(Net* n, int slot, size_t bytes, void** out);
 // pinned host buffer of at least `bytes` (grow-only; small transfers go through it without a pageable-copy stall)
+// a kept stream / a kept buffer of at least `bytes` (which: 0 features, 1 and 2 PCM); see Net::IdentifyKeep
+int net_keep_streams(Net* n, hipStream_t* compute, hipStream_t* copy);
+int net_keep_buffer(Net* n, int which, size_t bytes, void** out);
 int net_stage_pinned(Net* n, size_t bytes, void** out);
 // identify_speaker_list's vote counts for a long recording, tile by tile (stream.cpp).  pcm is a
 // host or a device pointer; counts_dev[out] / psums_dev[out] (either may be null) are added to.

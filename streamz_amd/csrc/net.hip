@@ -1643,6 +1643,9 @@ void net_destroy(Net* n)
     if (w.stat_slab) (void)hipFree(w.stat_slab);
     if (n->d_stats) (void)hipFree(n->d_stats);
     for (void* p : n->stage.dev) if (p) (void)hipFree(p);
+    for (void* p : n->keep.buf) if (p) (void)hipFree(p);
+    if (n->keep.compute) (void)hipStreamDestroy(n->keep.compute);
+    if (n->keep.copy) (void)hipStreamDestroy(n->keep.copy);
     if (n->stage.pinned) (void)hipHostFree(n->stage.pinned);
     delete n;
 }
@@ -2137,6 +2140,28 @@ int net_stage_dev(Net* n, int slot, size_t bytes, void** out)
         st.dev_cap[slot] = cap;
     }
     *out = st.dev[slot];
+    return SZH_OK;
+}
+
+int net_keep_streams(Net* n, hipStream_t* compute, hipStream_t* copy)
+{
+    if (!n->keep.compute) SZ_HIP(hipStreamCreateWithFlags(&n->keep.compute, hipStreamNonBlocking));
+    if (!n->keep.copy) SZ_HIP(hipStreamCreateWithFlags(&n->keep.copy, hipStreamNonBlocking));
+    *compute = n->keep.compute;
+    *copy = n->keep.copy;
+    return SZH_OK;
+}
+
+int net_keep_buffer(Net* n, int which, size_t bytes, void** out)
+{
+    Net::IdentifyKeep& k = n->keep;
+    if (k.cap[which] < bytes) {
+        if (k.buf[which]) { (void)hipFree(k.buf[which]); k.buf[which] = nullptr; k.cap[which] = 0; }
+        const size_t cap = (std::max<size_t>(bytes, 65536) + 65535) / 65536 * 65536;
+        SZ_HIP(hipMalloc(&k.buf[which], cap));
+        k.cap[which] = cap;
+    }
+    *out = k.buf[which];
     return SZH_OK;
 }
 

@@ -47,6 +47,7 @@ struct Resources {
     Plan *first = nullptr, *mid = nullptr, *last = nullptr;
     void* feat = nullptr;
     void* pcm[2] = {nullptr, nullptr};
+    bool kept_streams = false, kept_feat = false, kept_pcm = false;  // these belong to the net (Net::IdentifyKeep)
     ~Resources()
     {
         if (compute) (void)hipStreamSynchronize(compute);
@@ -66,14 +67,14 @@ struct Resources {
             if (graph[i]) (void)hipGraphDestroy(graph[i]);
             if (ready[i]) (void)hipEventDestroy(ready[i]);
             if (done[i]) (void)hipEventDestroy(done[i]);
-            if (pcm[i]) (void)hipFree(pcm[i]);
+            if (pcm[i] && !kept_pcm) (void)hipFree(pcm[i]);
         }
         plan_destroy(first);
         plan_destroy(mid);
         plan_destroy(last);
-        if (feat) (void)hipFree(feat);
-        if (compute) (void)hipStreamDestroy(compute);
-        if (copy) (void)hipStreamDestroy(copy);
+        if (feat && !kept_feat) (void)hipFree(feat);
+        if (compute && !kept_streams) (void)hipStreamDestroy(compute);
+        if (copy && !kept_streams) (void)hipStreamDestroy(copy);
     }
 };
 
@@ -117,8 +118,11 @@ int identify_tiled(Net* n, Extractor* e, const int16_t* pcm, bool pcm_on_device,
     if (B < 4) { set_error("tile_windows must be at least 4"); return SZH_EINVAL; }
     if (pcm_on_device && ((uintptr_t)pcm & 15) != 0) { set_error("device PCM must be 16-byte aligned"); return SZH_EINVAL; }
     Resources r;
-    SZ_HIP(hipDeviceSynchronize());  // the caller's work on other streams produced pcm / counts
-    SZ_HIP(hipStreamCreateWithFlags(&r.compute, hipStreamNonBlocking));
+    if (pcm_on_device) SZ_HIP(hipDeviceSynchronize());  // the caller's work on other streams produced pcm (the tallies were cleared on the net's compute stream)
+    // the net's own two streams (every caller holds the net's mutex)
+    int rc = net_keep_streams(n, &r.compute, &r.copy);
+    if (rc) return rc;
+    r.kept_streams = true;
     const bool single = nw <= B + 2;
     // tile layout: [first: B] [mid: B]* [last: 1 .. B+2]
     const uint64_t n_mid = single ? 0 : (nw - B - 3) / B;
@@ -137,13 +141,21 @@ int identify_tiled(Net* n, Extractor* e, const int16_t* pcm, bool pcm_on_device,
     uint64_t feat_rows = single ? nw : std::max<uint64_t>(B * max_lanes, last_rows);
     // (the one-kernel vote keeps no activations in memory: its net needs no rows of workspace beyond the minimum)
     const bool fused = net_vote_fused(n);
-    int rc = net_reserve_rows(n, fused ? 256 : feat_rows);
+    rc = net_reserve_rows(n, fused ? 256 : feat_rows);
     if (rc) return rc;
     if (!fused && max_lanes > 1 && net_workspace_rows(n) < B * max_lanes) {   // the reservation was capped
         max_lanes = std::max<uint64_t>(1, net_workspace_rows(n) / B);
         feat_rows = std::max<uint64_t>(B * max_lanes, last_rows);
     }
-    SZ_HIP(hipMalloc(&r.feat, feat_rows * kFeat * sizeof(float)));
+    // buffers of up to 32 MB stay with the net between calls
+    constexpr size_t kKeepLimit = 32u << 20;
+    if (feat_rows * kFeat * sizeof(float) <= kKeepLimit) {
+        rc = net_keep_buffer(n, 0, feat_rows * kFeat * sizeof(float), &r.feat);
+        if (rc) return rc;
+        r.kept_feat = true;
+    } else {
+        SZ_HIP(hipMalloc(&r.feat, feat_rows * kFeat * sizeof(float)));
+    }
     float* feat = static_cast<float*>(r.feat);
     // the weight images the vote kernel reads, once for all tiles (the lanes start after r.compute has drained)
     rc = net_vote_prepare(n, r.compute);
@@ -215,9 +227,15 @@ int identify_tiled(Net* n, Extractor* e, const int16_t* pcm, bool pcm_on_device,
     // PCM in host memory: tiles are staged through two device buffers; the copy of tile j+1
     // overlaps the kernels of tile j.
     const uint64_t buf_windows = single ? nw : std::max<uint64_t>(B + 4, last_rows + 2);
-    SZ_HIP(hipStreamCreateWithFlags(&r.copy, hipStreamNonBlocking));
+    r.kept_pcm = span(buf_windows) * sizeof(int16_t) <= kKeepLimit;
     for (int i = 0; i < 2; ++i) {
-        SZ_HIP(hipMalloc(&r.pcm[i], span(buf_windows) * sizeof(int16_t)));
+        if (r.kept_pcm) {
+            if (single && i == 1) continue;   // one piece: one buffer
+            rc = net_keep_buffer(n, 1 + i, span(buf_windows) * sizeof(int16_t), &r.pcm[i]);
+            if (rc) return rc;
+        } else {
+            SZ_HIP(hipMalloc(&r.pcm[i], span(buf_windows) * sizeof(int16_t)));
+        }
         SZ_HIP(hipEventCreateWithFlags(&r.ready[i], hipEventDisableTiming));
         SZ_HIP(hipEventCreateWithFlags(&r.done[i], hipEventDisableTiming));
     }
@@ -244,9 +262,13 @@ int identify_tiled(Net* n, Extractor* e, const int16_t* pcm, bool pcm_on_device,
             SZ_HIP(hipEventSynchronize(r.done[slot]));   // the host stays at most two tiles ahead of the GPU
             SZ_HIP(hipStreamWaitEvent(r.copy, r.done[slot], 0));
         }
-        SZ_HIP(hipMemcpyAsync(buf, pcm + s0, len * sizeof(int16_t), hipMemcpyHostToDevice, r.copy));
-        SZ_HIP(hipEventRecord(r.ready[slot], r.copy));
-        SZ_HIP(hipStreamWaitEvent(r.compute, r.ready[slot], 0));
+        if (single) {   // nothing to overlap with: the copy goes ahead of the kernels on their stream
+            SZ_HIP(hipMemcpyAsync(buf, pcm + s0, len * sizeof(int16_t), hipMemcpyHostToDevice, r.compute));
+        } else {
+            SZ_HIP(hipMemcpyAsync(buf, pcm + s0, len * sizeof(int16_t), hipMemcpyHostToDevice, r.copy));
+            SZ_HIP(hipEventRecord(r.ready[slot], r.copy));
+            SZ_HIP(hipStreamWaitEvent(r.compute, r.ready[slot], 0));
+        }
         if (is_first || is_last || prof_enabled()) {
             Plan* plan = is_first ? r.first : is_last ? r.last : r.mid;
             rc = run_tile(n, plan, buf, feat, rows, tally, r.compute);
