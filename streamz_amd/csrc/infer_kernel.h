@@ -16,13 +16,16 @@
 //   1. h1^T tiles (32 units x 32 rows, K = 64: the inputs, a one for the bias, zeros) are dealt to the
 //      waves; ReLU; written to LDS as h1[row][unit] (16-byte pieces, conflict-free);
 //   2. wave w computes h2^T for units 32 w .. 32 w + 31 over all of h1: its rows of w2^T come straight
-//      from global memory (L2), 16 bytes per lane and four steps, fetched four 32-unit trips ahead, from
-//      a copy of the weights laid out in fetch order (a wave's load reads 1 KB of consecutive memory; with
-//      the matrix as it lies, every lane of a load would touch a cache line of its own); one weight
-//      fragment multiplies all MT row blocks;
+//      from global memory (L2), 16 bytes per lane and four steps, two 32-unit trips in flight, from a copy
+//      of the weights laid out in fetch order (a wave's load reads 1 KB of consecutive memory; with the
+//      matrix as it lies, every lane of a load would touch a cache line of its own); one weight fragment
+//      multiplies all MT row blocks, whose activations are read from LDS one step ahead;
 //   3. partial logits^T over the wave's 32 units of h2 (w3 as the A operand), summed over the waves
 //      through LDS; softmax over a row's classes by 16 lanes (DPP), the last maximum wins, thresholded
 //      vote into an LDS histogram; per-class probability sums in f64.
+// On this part f32 matrix instructions and vector instructions take turns on a SIMD even when they belong to
+// different waves, so every vector instruction below is paid in matrix time: what can be a mask, an
+// instruction modifier or a table layout is not a branch, a copy or an address computation.
 // With MT = 1 a tile of 8192 rows is 256 workgroups, one per compute unit; each reads all weights once
 // (672 KB from L2 at 60-512-256-16), which is what 32 rows per compute unit cost; MT = 2 halves that for
 // calls with enough rows.
@@ -174,7 +177,7 @@ __global__ __launch_bounds__(kThreads) void infer_vote_kernel(Args a)
     for (int u = 0; u < 2 * NCT; ++u) b3v[u] = cl + 16 * u < a.C ? a.b3[cl + 16 * u] : 0.0f;
 
     const uint64_t n_tiles = (a.rows + 32 * MT - 1) / (32 * MT);
-    // A tile's rows are contiguous in memory: 8 MT in 16-byte pieces, piece e of the tile by thread e % 512.
+    // A tile's rows are contiguous in memory, 8 * MT * in pieces of 16 bytes; piece e of the tile goes with thread e % 512.
     // Pieces behind the last row repeat the last piece (their rows' results are not counted).
     const uint32_t tile_pieces = 8u * MT * (uint32_t)a.in;
     const uint64_t last_piece = a.rows * (uint64_t)a.in / 4 - 1;
