@@ -170,7 +170,7 @@ def other_figures(sz, ext, plan, pcm, feats, net_dims, n_win, dev, lr, dropout):
     rec = block.repeat((n_stream + block.numel() - 1) // block.numel())[:n_stream].contiguous()
     torch.cuda.synchronize()
     t_stream = None
-    for _ in range(2):
+    for _ in range(3):
         t0 = time.perf_counter()
         sz.identify_speaker_list_dev(net, rec.data_ptr(), n_stream, 0.5, ext)
         dt = time.perf_counter() - t0
