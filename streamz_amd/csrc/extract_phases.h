@@ -8,14 +8,19 @@
 // Scratch region R, in floats (kRegionFloats per window).  Everything aliases: a lane reads all it
 // needs from one layout into registers before any lane writes the next one (on the device the
 // LDS operations of a wavefront execute in program order; the emulator copies the region).
-//   [0, 400)    ten rows of Y[k1][n2] complex, row stride 40 floats: rows k1 = 0..9 first, and,
-//               once every lane holds its row of those, rows 10..19       (phase 1 -> phase 2)
-//   [0, 410)    power spectrum, bin k at pslot(k)                           (phase 2 -> phase 3)
+//   [0, 400)    ten rows of Y[k1][n2] complex as two planes of 200 floats -- the even columns n2 = 2u (lane u's
+//               first DFT) in [0, 200), the odd ones in [200, 400) -- row stride 20 floats, lane u at 2u: rows
+//               k1 = 0..9 first, and, once every lane holds its row of those, rows 10..19   (phase 1 -> phase 2)
+//   [3, 404)    power spectrum, bin k at pslot(k) = k + 3                   (phase 2 -> phase 3)
 //   [0, 330)    mel partial sums, (fall, rise) pairs, lane q at 33 q (an odd stride, so that
 //               the ten lanes hit different LDS banks)                      (phase 3 -> phase 4)
 //   [332, 358)  log mel energies                                            (phase 4 -> phase 5)
-// On the device consecutive windows' regions start kRegionStride floats apart, which shifts
-// each window by 4 banks against its neighbour.
+// On the device consecutive windows' regions start kRegionStride = 404 floats apart.  The layout and that
+// stride were chosen against LDS bank conflicts, which the counters put at 36 % of the LDS's busy cycles
+// with the layout before this one (rows of 40 interleaved floats, bins in runs of 41, regions 420 apart):
+// a store instruction of phase 1 now has its 16 lanes (one and a half windows) on 32 different banks,
+// 404 = 12 x 32 + 20 continuing where the 20 floats of the window before end; the 16-byte row and bin reads
+// of a lane group (lanes of three windows) fall on disjoint quadruples of the 64 banks.
 #pragma once
 #include <math.h>
 #include <stdint.h>
@@ -25,14 +30,16 @@
 
 namespace sz {
 
-constexpr int kRegionFloats = 412;
-constexpr int kRegionStride = 420;
-constexpr int kRowFloats = 40;
+constexpr int kRegionFloats = 404;
+constexpr int kRegionStride = 404;
+constexpr int kRowFloats = 20;     // one plane's row: ten lanes x one complex value
+constexpr int kPlaneFloats = 200;  // ten rows
 constexpr int kHalfRows = 10;      // rows of Y exchanged at a time
 constexpr int kPartOff = 0;
 constexpr int kLogOff = 332;
 static_assert(kPartOff + kGroup * kPairStride <= kLogOff && kLogOff + kMels <= kRegionFloats, "region layout");
-static_assert(kHalfRows * kRowFloats <= kRegionFloats && pslot(kBins - 1) < kRegionFloats, "region layout");
+static_assert(2 * kPlaneFloats <= kRegionFloats && kHalfRows * kRowFloats == kPlaneFloats && pslot(kBins - 1) < kRegionFloats, "region layout");
+static_assert(kRegionStride % 4 == 0 && (kPowerOff + 1) % 4 == 0, "16-byte reads of rows and bin runs");
 
 struct alignas(8) pcm4 { int16_t s[4]; };
 struct alignas(16) f4 { float v[4]; };
@@ -68,7 +75,7 @@ SZ_HD void phase1(int u, const int16_t* win, float* R, const TT* T, v2f (&hi_a)[
 #pragma unroll
         for (int k1 = 0; k1 < 20; ++k1) {
             const v2f y = cmul(A[k1], mk(T->twa[k1][u][0], T->twa[k1][u][1]));
-            if (k1 < kHalfRows) *reinterpret_cast<v2f*>(R + k1 * kRowFloats + 4 * u) = y;
+            if (k1 < kHalfRows) *reinterpret_cast<v2f*>(R + k1 * kRowFloats + 2 * u) = y;
             else hi_a[k1 - kHalfRows] = y;
         }
     }
@@ -81,7 +88,7 @@ SZ_HD void phase1(int u, const int16_t* win, float* R, const TT* T, v2f (&hi_a)[
 #pragma unroll
         for (int k1 = 0; k1 < 20; ++k1) {
             const v2f y = cmul(B[k1], mk(T->twb[k1][u][0], T->twb[k1][u][1]));
-            if (k1 < kHalfRows) *reinterpret_cast<v2f*>(R + k1 * kRowFloats + 4 * u + 2) = y;
+            if (k1 < kHalfRows) *reinterpret_cast<v2f*>(R + kPlaneFloats + k1 * kRowFloats + 2 * u) = y;
             else hi_b[k1 - kHalfRows] = y;
         }
     }
@@ -92,8 +99,8 @@ SZ_HD void phase1_high(int u, float* R, const v2f (&hi_a)[kHalfRows], const v2f 
 {
 #pragma unroll
     for (int k = 0; k < kHalfRows; ++k) {
-        *reinterpret_cast<v2f*>(R + k * kRowFloats + 4 * u) = hi_a[k];
-        *reinterpret_cast<v2f*>(R + k * kRowFloats + 4 * u + 2) = hi_b[k];
+        *reinterpret_cast<v2f*>(R + k * kRowFloats + 2 * u) = hi_a[k];
+        *reinterpret_cast<v2f*>(R + kPlaneFloats + k * kRowFloats + 2 * u) = hi_b[k];
     }
 }
 
@@ -102,13 +109,17 @@ SZ_HD int first_row(int u) { return u; }
 // its row of the second half, as an index into the stored rows 10..19
 SZ_HD int second_row(int u) { return u == 0 ? 0 : kHalfRows - u; }
 
+// row `row` of Y, columns n2 = 0..19 in order: the even columns from the first plane, the odd ones from the second
 SZ_HD void read_row(const float* R, int row, v2f (&x)[20])
 {
 #pragma unroll
-    for (int j = 0; j < 10; ++j) {
-        const f4 q = *reinterpret_cast<const f4*>(R + row * kRowFloats + 4 * j);
-        x[2 * j] = mk(q.v[0], q.v[1]);
-        x[2 * j + 1] = mk(q.v[2], q.v[3]);
+    for (int j = 0; j < 5; ++j) {
+        const f4 e = *reinterpret_cast<const f4*>(R + row * kRowFloats + 4 * j);
+        const f4 o = *reinterpret_cast<const f4*>(R + kPlaneFloats + row * kRowFloats + 4 * j);
+        x[4 * j] = mk(e.v[0], e.v[1]);
+        x[4 * j + 1] = mk(o.v[0], o.v[1]);
+        x[4 * j + 2] = mk(e.v[2], e.v[3]);
+        x[4 * j + 3] = mk(o.v[2], o.v[3]);
     }
 }
 
@@ -164,7 +175,11 @@ SZ_HD void phase2(int u, float* R, const TT* T, const v2f (&x0)[20])
 SZ_HD void phase3_load(int q, const float* R, float (&p)[kMelSteps])
 {
 #pragma unroll
-    for (int st = 0; st < kMelSteps; ++st) p[st] = R[(kMelSteps + 1) * q + 1 + st];  // pslot(40 q + 1 + st)
+    for (int j = 0; j < kMelSteps / 4; ++j) {
+        const f4 v = *reinterpret_cast<const f4*>(R + kMelSteps * q + kPowerOff + 1 + 4 * j);  // pslot(40 q + 1 + 4 j ...)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) p[4 * j + i] = v.v[i];
+    }
 }
 
 template <class TT>

@@ -37,9 +37,11 @@ constexpr int kPairStride = 2 * kMaxPairs + 1;  // floats between two lanes' par
 constexpr int kMaxComb = 8;
 constexpr int kZeroSlot = 2 * kMaxPairs;  // relative to lane 0's partial array: its padding float, kept 0
 
-// Slot of power bin k (0..400) in a window's scratch region: k plus the number of complete
-// 40-bin runs before it, so that lanes sweeping neighbouring runs hit different LDS banks.
-constexpr int pslot(int k) { return k <= 40 ? k : k + (k - 1) / 40; }
+// Slot of power bin k (0..400) in a window's scratch region: bin 1, where lane 0's run of 40 bins starts, lies
+// 16-byte aligned, so that a mel lane fetches its run with ten 16-byte reads (which, with the regions 404 floats
+// apart, are free of bank conflicts; so are most of the scattered stores of the bins).
+constexpr int kPowerOff = 3;
+constexpr int pslot(int k) { return k + kPowerOff; }
 
 struct MelStep {
     float wf;       // weight into the falling-edge accumulator
