@@ -10,7 +10,7 @@ import numpy as np
 FEATURE_SIZE = 60
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libstreamz_hip.so")
+_SO = os.environ.get("STREAMZ_HIP_LIBRARY") or os.path.join(_HERE, "libstreamz_hip.so")   # (the override is for A/B timing of two builds)
 _lib = None
 
 

@@ -844,8 +844,8 @@ static int tally_pcm(Net* n, Extractor* e, const int16_t* pcm, bool on_device, u
     unsigned long long* d_cnt = static_cast<unsigned long long*>(d_tally);
     double* d_sum = reinterpret_cast<double*>(static_cast<char*>(d_tally) + cnt_bytes);
     // cleared on the stream the first tile's kernels run on (identify_tiled takes the same one from the net)
-    hipStream_t compute = nullptr, copy = nullptr;
-    rc = net_keep_streams(n, &compute, &copy);
+    hipStream_t compute = nullptr;
+    rc = net_keep_stream(n, &compute);
     if (rc) return rc;
     SZ_HIP(hipMemsetAsync(d_tally, 0, cnt_bytes + sum_bytes, compute));
     rc = identify_tiled(n, e, pcm, on_device, n_samples, threshold, tile, counts ? d_cnt : nullptr, sums ? d_sum : nullptr);

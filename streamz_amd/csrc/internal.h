@@ -120,11 +120,11 @@ struct Net {
     std::mutex mu;              // serialises host-API calls that share the workspace
     Workspace ws;
     Staging stage;              // guarded by mu
-    // What identify_speaker* keeps between calls (guarded by mu): two streams, and the buffers of recordings
+    // What identify_speaker* keeps between calls (guarded by mu): its stream, and the buffers of recordings
     // short enough to go through in one piece -- a call on a one-second clip otherwise spends most of its time
     // creating and destroying them.
     struct IdentifyKeep {
-        hipStream_t compute = nullptr, copy = nullptr;
+        hipStream_t compute = nullptr;
         void* buf[3] = {};       // features, two PCM staging buffers
         size_t cap[3] = {};
     } keep;
@@ -208,8 +208,8 @@ uint64_t net_workspace_rows(const Net* n);
 // device buffer `slot` of at least `bytes` (grow-only, owned by the net; call with n->mu held)
 int net_stage_dev(Net* n, int slot, size_t bytes, void** out);
 // pinned host buffer of at least `bytes` (grow-only; small transfers go through it without a pageable-copy stall)
-// a kept stream / a kept buffer of at least `bytes` (which: 0 features, 1 and 2 PCM); see Net::IdentifyKeep
-int net_keep_streams(Net* n, hipStream_t* compute, hipStream_t* copy);
+// the kept stream / a kept buffer of at least `bytes` (which: 0 features, 1 and 2 PCM); see Net::IdentifyKeep
+int net_keep_stream(Net* n, hipStream_t* compute);
 int net_keep_buffer(Net* n, int which, size_t bytes, void** out);
 int net_stage_pinned(Net* n, size_t bytes, void** out);
 // identify_speaker_list's vote counts for a long recording, tile by tile (stream.cpp).  pcm is a

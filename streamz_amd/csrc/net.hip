@@ -1645,7 +1645,6 @@ void net_destroy(Net* n)
     for (void* p : n->stage.dev) if (p) (void)hipFree(p);
     for (void* p : n->keep.buf) if (p) (void)hipFree(p);
     if (n->keep.compute) (void)hipStreamDestroy(n->keep.compute);
-    if (n->keep.copy) (void)hipStreamDestroy(n->keep.copy);
     if (n->stage.pinned) (void)hipHostFree(n->stage.pinned);
     delete n;
 }
@@ -2143,12 +2142,10 @@ int net_stage_dev(Net* n, int slot, size_t bytes, void** out)
     return SZH_OK;
 }
 
-int net_keep_streams(Net* n, hipStream_t* compute, hipStream_t* copy)
+int net_keep_stream(Net* n, hipStream_t* compute)
 {
     if (!n->keep.compute) SZ_HIP(hipStreamCreateWithFlags(&n->keep.compute, hipStreamNonBlocking));
-    if (!n->keep.copy) SZ_HIP(hipStreamCreateWithFlags(&n->keep.copy, hipStreamNonBlocking));
     *compute = n->keep.compute;
-    *copy = n->keep.copy;
     return SZH_OK;
 }
 

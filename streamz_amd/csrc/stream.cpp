@@ -47,7 +47,7 @@ struct Resources {
     Plan *first = nullptr, *mid = nullptr, *last = nullptr;
     void* feat = nullptr;
     void* pcm[2] = {nullptr, nullptr};
-    bool kept_streams = false, kept_feat = false, kept_pcm = false;  // these belong to the net (Net::IdentifyKeep)
+    bool kept_feat = false, kept_pcm = false;  // these belong to the net (Net::IdentifyKeep), as `compute` does
     ~Resources()
     {
         if (compute) (void)hipStreamSynchronize(compute);
@@ -59,7 +59,7 @@ struct Resources {
             if (lane_exec[i]) (void)hipGraphExecDestroy(lane_exec[i]);
             if (lane_graph[i]) (void)hipGraphDestroy(lane_graph[i]);
             plan_destroy(lane_plan[i]);
-            if (lane_stream[i]) (void)hipStreamDestroy(lane_stream[i]);
+            if (lane_stream[i] && lane_stream[i] != compute) (void)hipStreamDestroy(lane_stream[i]);
         }
         if (net) net->ws.row_base = 0;
         for (int i = 0; i < 2; ++i) {
@@ -73,8 +73,7 @@ struct Resources {
         plan_destroy(mid);
         plan_destroy(last);
         if (feat && !kept_feat) (void)hipFree(feat);
-        if (compute && !kept_streams) (void)hipStreamDestroy(compute);
-        if (copy && !kept_streams) (void)hipStreamDestroy(copy);
+        if (copy) (void)hipStreamDestroy(copy);
     }
 };
 
@@ -119,10 +118,11 @@ int identify_tiled(Net* n, Extractor* e, const int16_t* pcm, bool pcm_on_device,
     if (pcm_on_device && ((uintptr_t)pcm & 15) != 0) { set_error("device PCM must be 16-byte aligned"); return SZH_EINVAL; }
     Resources r;
     if (pcm_on_device) SZ_HIP(hipDeviceSynchronize());  // the caller's work on other streams produced pcm (the tallies were cleared on the net's compute stream)
-    // the net's own two streams (every caller holds the net's mutex)
-    int rc = net_keep_streams(n, &r.compute, &r.copy);
+    // the net's own stream (every caller holds the net's mutex).  A second one, for the copies of a long host
+    // recording, is made per call where it is needed: a stream that is kept holds on to one of the process's
+    // four hardware queues, and the lanes below want one queue each.
+    int rc = net_keep_stream(n, &r.compute);
     if (rc) return rc;
-    r.kept_streams = true;
     const bool single = nw <= B + 2;
     // tile layout: [first: B] [mid: B]* [last: 1 .. B+2]
     const uint64_t n_mid = single ? 0 : (nw - B - 3) / B;
@@ -189,8 +189,16 @@ int identify_tiled(Net* n, Extractor* e, const int16_t* pcm, bool pcm_on_device,
             // `lanes` tiles per replay; its features and its workspace rows are the l-th range of B rows.
             const int lanes = (int)std::min<uint64_t>(std::min<uint64_t>(n_mid, (uint64_t)max_lanes), kMaxLanes);
             r.net = n;
+            // the first tile (direct launches on r.compute) used the rows of lane 0
+            SZ_HIP(hipStreamSynchronize(r.compute));
             for (int l = 0; l < lanes; ++l) {
-                SZ_HIP(hipStreamCreateWithFlags(&r.lane_stream[l], hipStreamNonBlocking));
+                // The last lane runs on the net's own stream, the others on streams of this call: with the null
+                // stream that makes four streams for three lanes, one per hardware queue of the process (HIP's
+                // default is four).  A fifth stream is given a queue that another one already has, and which
+                // one is not ours to choose: with two lanes on one queue, 190 instead of 254 M windows/s at
+                // tiles of 8192 windows.
+                if (l == lanes - 1) r.lane_stream[l] = r.compute;
+                else SZ_HIP(hipStreamCreateWithFlags(&r.lane_stream[l], hipStreamNonBlocking));
                 rc = plan_create_tile(e, (B - 2 + (uint64_t)l * B) * kHop, 2, (uint32_t)B, 2, &r.lane_plan[l]);
                 if (rc == SZH_OK) rc = plan_set_advance(r.lane_plan[l], (uint64_t)lanes * B * kHop);
                 if (rc) return rc;
@@ -204,8 +212,6 @@ int identify_tiled(Net* n, Extractor* e, const int16_t* pcm, bool pcm_on_device,
                 SZ_HIP(hipGraphInstantiate(&r.lane_exec[l], r.lane_graph[l], nullptr, nullptr, 0));
                 for (int k = 0; k < kReplayDepth; ++k) SZ_HIP(hipEventCreateWithFlags(&r.lane_done[l][k], hipEventDisableTiming));
             }
-            // the first tile (direct launches on r.compute) used the rows of lane 0
-            SZ_HIP(hipStreamSynchronize(r.compute));
             for (uint64_t t = 0; t < n_mid; ++t) {
                 const int l = (int)(t % lanes);
                 const int slot = (int)((t / lanes) % kReplayDepth);
@@ -227,6 +233,7 @@ int identify_tiled(Net* n, Extractor* e, const int16_t* pcm, bool pcm_on_device,
     // PCM in host memory: tiles are staged through two device buffers; the copy of tile j+1
     // overlaps the kernels of tile j.
     const uint64_t buf_windows = single ? nw : std::max<uint64_t>(B + 4, last_rows + 2);
+    if (!single) SZ_HIP(hipStreamCreateWithFlags(&r.copy, hipStreamNonBlocking));
     r.kept_pcm = span(buf_windows) * sizeof(int16_t) <= kKeepLimit;
     for (int i = 0; i < 2; ++i) {
         if (r.kept_pcm) {

@@ -1,8 +1,8 @@
-"""identify_speaker_list over 100 h of device-resident PCM in tiles of 8192 and 32768 windows, with the number
+"""identify_speaker_list over 100 h of device-resident PCM in tiles of TILES (default 8192,32768) windows, with the number
 of tiles in flight taken from STREAMZ_TILE_LANES (1..4); the votes must not depend on it."""
 import os, sys, time
 import numpy as np, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import streamz_amd as sz
 n_samples = int(100 * 3600 * 44100)
 nw = sz.window_count(n_samples)
