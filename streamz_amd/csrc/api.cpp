@@ -85,17 +85,49 @@ int extract_files_host(Extractor* e, const int16_t* const* pcm, const uint64_t* 
     if (rc) return rc;
     rc = d_feat.alloc(plan->total_windows * kFeat * sizeof(float));
     if (rc) return rc;
-    for (uint32_t f = 0; f < n_files; ++f)
-        if (len[f] >= (uint64_t)kWindow)
-            SZ_HIP(hipMemcpy(d_pcm.as<int16_t>() + off[f], pcm[f], len[f] * sizeof(int16_t), hipMemcpyHostToDevice));
+    // From 32 MB of PCM on, the files go to the device through pinned pieces filled by helper threads, one
+    // pipeline across all files (host_copy.cpp): about twice the rate of pageable copies.
+    constexpr size_t kStagedBytes = 32u << 20, kRingBytes = 32u << 20, kPieceBytes = 4u << 20;
+    struct Pinned { void* p = nullptr; ~Pinned() { if (p) (void)hipHostFree(p); } } ring;
+    HostStager stager;   // (declared after the ring: it is finished before the ring is freed)
+    if (total * sizeof(int16_t) >= kStagedBytes && HostStager::helpers_wanted() > 0) {
+        SZ_HIP(hipHostMalloc(&ring.p, kRingBytes, hipHostMallocDefault));
+        rc = stager.start(ring.p, kRingBytes, kPieceBytes, HostStager::helpers_wanted());
+        if (rc) return rc;
+    }
+    if (stager.started()) {
+        std::vector<HostStager::Span> spans;
+        for (uint32_t f = 0; f < n_files; ++f)
+            if (len[f] >= (uint64_t)kWindow) spans.push_back({d_pcm.as<int16_t>() + off[f], pcm[f], len[f] * sizeof(int16_t)});
+        rc = stager.copy_many(spans.data(), spans.size(), nullptr);
+        if (rc) return rc;
+    } else {
+        for (uint32_t f = 0; f < n_files; ++f)
+            if (len[f] >= (uint64_t)kWindow)
+                SZ_HIP(hipMemcpy(d_pcm.as<int16_t>() + off[f], pcm[f], len[f] * sizeof(int16_t), hipMemcpyHostToDevice));
+    }
+    stager.finish();
     rc = plan_run(plan, d_pcm.as<int16_t>(), d_feat.as<float>(), nullptr);
     if (rc) return rc;
-    SZ_HIP(hipStreamSynchronize(nullptr));
+    // the features come back the same way (a pageable copy into pages the host has not touched yet is slower still)
+    HostStager back;
+    if (ring.p) {
+        rc = back.start(ring.p, kRingBytes, kPieceBytes, HostStager::helpers_wanted(), true);
+        if (rc) return rc;
+    } else {
+        SZ_HIP(hipStreamSynchronize(nullptr));
+    }
+    std::vector<HostStager::Span> spans;
     for (uint32_t f = 0; f < n_files; ++f) {
         const uint64_t nw = plan->win_off[f + 1] - plan->win_off[f];
-        if (nw)
-            SZ_HIP(hipMemcpy(out[f], d_feat.as<float>() + plan->win_off[f] * kFeat, nw * kFeat * sizeof(float),
-                             hipMemcpyDeviceToHost));
+        if (!nw) continue;
+        const float* src = d_feat.as<float>() + plan->win_off[f] * kFeat;
+        if (ring.p) spans.push_back({out[f], src, nw * kFeat * sizeof(float)});
+        else SZ_HIP(hipMemcpy(out[f], src, nw * kFeat * sizeof(float), hipMemcpyDeviceToHost));
+    }
+    if (ring.p) {
+        rc = back.copy_many(spans.data(), spans.size(), nullptr);
+        if (rc) return rc;
     }
     return SZH_OK;
 }
@@ -818,13 +850,14 @@ int szh_identify_from_features(szh_net* net, const float* feats, uint64_t n_wind
 }
 
 // Windows per tile of a long recording; recordings of up to two tiles go through in one piece.
-// Device-resident PCM through the one-kernel vote has no per-tile intermediates to keep in L2, and larger tiles
-// amortise the launches (100 h, M windows/s: 8192: 250, 65536: 292, 262144: 300).
-static uint32_t tile_windows_default(bool resident_fused = false)
+// Through the one-kernel vote a tile has no intermediates to keep in L2, and larger tiles amortise the launches
+// (100 h of device-resident PCM, M windows/s: 8192: 254, 65536: 296, 262144: 305) and the per-tile hand-over
+// between the copy and the kernels of a host recording (10 h, GB/s of PCM: 8192: 40, 65536: 50).
+static uint32_t tile_windows_default(bool fused, bool resident)
 {
     const char* v = std::getenv("STREAMZ_TILE_WINDOWS");
     const long long t = v ? std::atoll(v) : 0;
-    return t >= 4 && t <= (1ll << 24) ? (uint32_t)t : resident_fused ? 262144u : 8192u;
+    return t >= 4 && t <= (1ll << 24) ? (uint32_t)t : !fused ? 8192u : resident ? 262144u : 65536u;
 }
 
 // Votes and / or probability sums of a recording (host or device PCM), read back to the host.
@@ -872,9 +905,9 @@ static int identify_pcm(Net* n, Extractor* e, const int16_t* pcm, bool on_device
 }
 
 // windows per tile for a host recording of nw windows: up to two tiles go through in one piece
-static uint32_t host_tile(uint64_t nw)
+static uint32_t host_tile(const Net* n, uint64_t nw)
 {
-    const uint32_t tile = tile_windows_default();
+    const uint32_t tile = tile_windows_default(net_vote_fused(n), false);
     return nw <= 2ull * tile ? (uint32_t)std::max<uint64_t>(nw, 4) : tile;
 }
 
@@ -905,7 +938,7 @@ int szh_identify_speaker_list(szh_net* net, szh_extractor* ext, const int16_t* p
     SZ_TRY
     if (!net || !ext || !n_ids || (n_samples && !pcm)) { set_error("null argument"); return SZH_EINVAL; }
     return identify_pcm(reinterpret_cast<Net*>(net), reinterpret_cast<Extractor*>(ext), pcm, false, n_samples, threshold,
-                        host_tile(szh_window_count(n_samples)), ids, capacity, n_ids, nullptr);
+                        host_tile(reinterpret_cast<Net*>(net), szh_window_count(n_samples)), ids, capacity, n_ids, nullptr);
     SZ_CATCH
 }
 
@@ -916,7 +949,7 @@ int szh_identify_speaker(szh_net* net, szh_extractor* ext, const int16_t* pcm, u
     if (!net || !ext || !id || (n_samples && !pcm)) { set_error("null argument"); return SZH_EINVAL; }
     std::vector<double> s;
     const int rc = tally_pcm(reinterpret_cast<Net*>(net), reinterpret_cast<Extractor*>(ext), pcm, false, n_samples, 0.0f,
-                             host_tile(szh_window_count(n_samples)), nullptr, &s);
+                             host_tile(reinterpret_cast<Net*>(net), szh_window_count(n_samples)), nullptr, &s);
     if (rc) return rc;
     *id = best_of_sums(s, sums);
     return SZH_OK;
@@ -931,7 +964,7 @@ int szh_identify_speaker_with_threshold(szh_net* net, szh_extractor* ext, const 
     std::vector<double> s;
     const uint64_t nw = szh_window_count(n_samples);
     const int rc = tally_pcm(reinterpret_cast<Net*>(net), reinterpret_cast<Extractor*>(ext), pcm, false, n_samples, 0.0f,
-                             host_tile(nw), nullptr, &s);
+                             host_tile(reinterpret_cast<Net*>(net), nw), nullptr, &s);
     if (rc) return rc;
     *id = thresholded(s, nw, threshold, nullptr);
     return SZH_OK;
@@ -971,7 +1004,7 @@ int szh_identify_speaker_list_dev(szh_net* net, szh_extractor* ext, const int16_
     if (!net || !ext || !n_ids || (n_samples && !pcm_dev)) { set_error("null argument"); return SZH_EINVAL; }
     Net* n = reinterpret_cast<Net*>(net);
     return identify_pcm(n, reinterpret_cast<Extractor*>(ext), pcm_dev, true, n_samples, threshold,
-                        tile_windows ? tile_windows : tile_windows_default(net_vote_fused(n)), ids, capacity, n_ids, counts);
+                        tile_windows ? tile_windows : tile_windows_default(net_vote_fused(n), true), ids, capacity, n_ids, counts);
     SZ_CATCH
 }
 

@@ -208,6 +208,31 @@ uint64_t net_workspace_rows(const Net* n);
 // device buffer `slot` of at least `bytes` (grow-only, owned by the net; call with n->mu held)
 int net_stage_dev(Net* n, int slot, size_t bytes, void** out);
 // pinned host buffer of at least `bytes` (grow-only; small transfers go through it without a pageable-copy stall)
+// Pageable host memory to device memory, or back, through a ring of pinned slots and helper threads (host_copy.cpp):
+// start() takes the ring (pinned, owned by the caller, must outlive finish()), the direction, and starts the
+// helpers.  To the device, copy() returns once every piece of the source has been handed to the stream (the last
+// ones may still be in flight); to the host, once the destination holds the data.  finish() stops the helpers and
+// waits until the ring is no longer in use.  One thread calls copy() at a time.
+class HostStager {
+public:
+    HostStager();
+    ~HostStager();
+    HostStager(const HostStager&) = delete;
+    HostStager& operator=(const HostStager&) = delete;
+    // helper threads to use: STREAMZ_COPY_THREADS (0 = plain pageable copies, at most 8), 3 by default
+    static int helpers_wanted();
+    int start(void* pinned_ring, size_t ring_bytes, size_t piece_bytes, int helpers, bool to_host = false);
+    bool started() const { return impl_ != nullptr; }
+    int copy(void* dst, const void* src, size_t bytes, hipStream_t s);
+    // several copies as one pipeline (the helpers run on into the next span while the first is still in flight)
+    struct Span { void* dst; const void* src; size_t bytes; };
+    int copy_many(const Span* spans, size_t n_spans, hipStream_t s);
+    void finish();
+private:
+    struct Impl;
+    Impl* impl_ = nullptr;
+};
+
 // the kept stream / a kept buffer of at least `bytes` (which: 0 features, 1 and 2 PCM); see Net::IdentifyKeep
 int net_keep_stream(Net* n, hipStream_t* compute);
 int net_keep_buffer(Net* n, int which, size_t bytes, void** out);

@@ -29,6 +29,8 @@ constexpr int kMaxLanes = 4;   // tiles of device-resident PCM kept in flight at
 // image -- seen in an earlier round, cause not established, so nothing here relies on a "safe" depth
 // having been measured.
 constexpr int kReplayDepth = 16;
+// host recordings of at least kStagedCopyBytes are copied through kRingBytes of pinned memory in pieces of kPieceBytes
+constexpr size_t kStagedCopyBytes = 32u << 20, kRingBytes = 32u << 20, kPieceBytes = 4u << 20;
 
 struct Resources {
     hipStream_t compute = nullptr, copy = nullptr;
@@ -48,8 +50,10 @@ struct Resources {
     void* feat = nullptr;
     void* pcm[2] = {nullptr, nullptr};
     bool kept_feat = false, kept_pcm = false;  // these belong to the net (Net::IdentifyKeep), as `compute` does
+    HostStager stager;                         // long host recordings: copies staged through the net's pinned buffer
     ~Resources()
     {
+        stager.finish();
         if (compute) (void)hipStreamSynchronize(compute);
         if (copy) (void)hipStreamSynchronize(copy);
         for (int i = 0; i < kMaxLanes; ++i) {
@@ -147,8 +151,8 @@ int identify_tiled(Net* n, Extractor* e, const int16_t* pcm, bool pcm_on_device,
         max_lanes = std::max<uint64_t>(1, net_workspace_rows(n) / B);
         feat_rows = std::max<uint64_t>(B * max_lanes, last_rows);
     }
-    // buffers of up to 32 MB stay with the net between calls
-    constexpr size_t kKeepLimit = 32u << 20;
+    // feature buffers of up to 32 MB and PCM staging buffers of up to 128 MB stay with the net between calls
+    constexpr size_t kKeepLimit = 32u << 20, kKeepLimitPcm = 128u << 20;
     if (feat_rows * kFeat * sizeof(float) <= kKeepLimit) {
         rc = net_keep_buffer(n, 0, feat_rows * kFeat * sizeof(float), &r.feat);
         if (rc) return rc;
@@ -234,7 +238,18 @@ int identify_tiled(Net* n, Extractor* e, const int16_t* pcm, bool pcm_on_device,
     // overlaps the kernels of tile j.
     const uint64_t buf_windows = single ? nw : std::max<uint64_t>(B + 4, last_rows + 2);
     if (!single) SZ_HIP(hipStreamCreateWithFlags(&r.copy, hipStreamNonBlocking));
-    r.kept_pcm = span(buf_windows) * sizeof(int16_t) <= kKeepLimit;
+    // From 32 MB of PCM on, the copies go through a ring of pinned pieces filled by helper threads: twice the rate
+    // of a pageable hipMemcpyAsync (host_copy.cpp).  Below that the threads' start-up would show.
+    if (n_samples * sizeof(int16_t) >= kStagedCopyBytes) {
+        const int helpers = HostStager::helpers_wanted();
+        if (helpers > 0) {
+            void* ring = nullptr;
+            rc = net_stage_pinned(n, kRingBytes, &ring);
+            if (rc == SZH_OK) rc = r.stager.start(ring, kRingBytes, kPieceBytes, helpers);
+            if (rc) return rc;
+        }
+    }
+    r.kept_pcm = span(buf_windows) * sizeof(int16_t) <= kKeepLimitPcm;
     for (int i = 0; i < 2; ++i) {
         if (r.kept_pcm) {
             if (single && i == 1) continue;   // one piece: one buffer
@@ -269,10 +284,14 @@ int identify_tiled(Net* n, Extractor* e, const int16_t* pcm, bool pcm_on_device,
             SZ_HIP(hipEventSynchronize(r.done[slot]));   // the host stays at most two tiles ahead of the GPU
             SZ_HIP(hipStreamWaitEvent(r.copy, r.done[slot], 0));
         }
-        if (single) {   // nothing to overlap with: the copy goes ahead of the kernels on their stream
-            SZ_HIP(hipMemcpyAsync(buf, pcm + s0, len * sizeof(int16_t), hipMemcpyHostToDevice, r.compute));
-        } else {
-            SZ_HIP(hipMemcpyAsync(buf, pcm + s0, len * sizeof(int16_t), hipMemcpyHostToDevice, r.copy));
+        if (r.stager.started()) {
+            rc = r.stager.copy(buf, pcm + s0, len * sizeof(int16_t), single ? r.compute : r.copy);
+            if (rc) return rc;
+            if (is_last) r.stager.finish();
+        } else {   // (one piece has nothing to overlap with: its copy goes ahead of the kernels on their stream)
+            SZ_HIP(hipMemcpyAsync(buf, pcm + s0, len * sizeof(int16_t), hipMemcpyHostToDevice, single ? r.compute : r.copy));
+        }
+        if (!single) {
             SZ_HIP(hipEventRecord(r.ready[slot], r.copy));
             SZ_HIP(hipStreamWaitEvent(r.compute, r.ready[slot], 0));
         }

@@ -5,7 +5,7 @@ import streamz_amd as sz
 net = sz.SimpleNeuralNet(60, 512, 256, 16, seed=7)
 ext = sz.FeatureExtractor()
 rng = np.random.default_rng(3)
-for secs in ((1,) if os.environ.get("ONLY") else (1, 10, 60, 600)):
+for secs in (tuple(int(v) for v in os.environ["ONLY"].split(",")) if os.environ.get("ONLY") else (1, 10, 60, 600)):
     pcm = np.clip(np.round(0.3 * rng.standard_normal(int(secs * 44100)) * 32767), -32768, 32767).astype(np.int16)
     for _ in range(3): sz.identify_speaker_list(net, pcm, 0.5, ext)
     t0 = time.perf_counter(); n = 50
