@@ -175,7 +175,17 @@ def other_figures(sz, ext, plan, pcm, feats, net_dims, n_win, dev, lr, dropout):
         sz.identify_speaker_list_dev(net, rec.data_ptr(), n_stream, 0.5, ext)
         dt = time.perf_counter() - t0
         t_stream = dt if t_stream is None else min(t_stream, dt)
+    # the same call as the Rust host makes it, on a slice in pageable host memory (10 h: 3.2 GB): bound by the copy
+    n_host = 10 * 3600 * 44100
+    rec_host = rec[:n_host].cpu().numpy()
     del rec
+    t_host = None
+    for _ in range(2):
+        t0 = time.perf_counter()
+        sz.identify_speaker_list(net, rec_host, 0.5, ext)
+        dt = time.perf_counter() - t0
+        t_host = dt if t_host is None else min(t_host, dt)
+    del rec_host
     # flops of one window's forward pass (lib.rs:880-891): the three layers' multiply-adds
     fwd_flops = 2 * (net_dims[0] * net_dims[1] + net_dims[1] * net_dims[2] + net_dims[2] * net_dims[3])
 
@@ -190,6 +200,9 @@ def other_figures(sz, ext, plan, pcm, feats, net_dims, n_win, dev, lr, dropout):
             "identify_100h_seconds": t_stream,
             "identify_100h_note": "configs[3]: identify_speaker_list over 100 h of PCM resident in HBM, tiles of 262144 "
                                   "windows, one HIP graph replay per tile, votes read once at the end",
+            "identify_10h_from_host_windows_per_s": sz.window_count(n_host) / t_host,
+            "identify_10h_from_host_note": "identify_speaker_list on 10 h of PCM in pageable host memory, the PCIe copy inside the call "
+                                           "(%.1f GB/s of PCM; staged through pinned memory by helper threads)" % (n_host * 2 / t_host / 1e9),
             "infer_windows_per_s": n_win / t_inf,
             "infer_note": "extract + forward + thresholded vote (lib.rs:1383-1411) over all clips, device-resident",
             "cli_batch8_train_windows_per_s": n_b8 / t_b8,

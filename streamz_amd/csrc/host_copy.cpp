@@ -103,15 +103,17 @@ struct HostStager::Impl {
     bool helper_done(uint64_t g) const { return copied[g % slots].load(std::memory_order_acquire) >= g + 1; }
 
     // to the device: frees slots whose latest transfer has completed.  to the host: hands over slots whose data
-    // has arrived.  Never blocks.
-    void advance_ready()
+    // has arrived.  Never blocks; anything but "done" or "not yet" from the event is an error.
+    hipError_t advance_ready()
     {
         for (;;) {
             const uint64_t r = ready.load(std::memory_order_relaxed);
-            if (to_host) {
-                if (r >= enqueued || hipEventQuery(sent[r % slots]) != hipSuccess) return;
-            } else if (r >= (uint64_t)slots) {   // (the first use of a slot needs no wait)
-                if (r - slots >= enqueued || hipEventQuery(sent[r % slots]) != hipSuccess) return;
+            const bool needs_event = to_host || r >= (uint64_t)slots;   // (the first use of a slot needs no wait)
+            if (needs_event) {
+                if ((to_host ? r : r - slots) >= enqueued) return hipSuccess;
+                const hipError_t q = hipEventQuery(sent[r % slots]);
+                if (q == hipErrorNotReady) return hipSuccess;
+                if (q != hipSuccess) return q;
             }
             ready.store(r + 1, std::memory_order_release);
         }
@@ -178,7 +180,7 @@ int HostStager::copy_many(const Span* spans, size_t n_spans, hipStream_t s)
     Backoff b;
     while (im.enqueued < end || (im.to_host && finished < end)) {
         bool progress = false;
-        im.advance_ready();
+        SZ_HIP(im.advance_ready());
         const uint64_t g = im.enqueued;
         // the next transfer: its slot must hold the filled piece (to the device) or be drained of the piece that
         // used it before (to the host)
